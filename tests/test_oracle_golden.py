@@ -1,0 +1,196 @@
+"""Pins the ORACLE (oracle/) to the reference: every function is checked against vectors produced by the
+reference's own code (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: integer / index outputs and the C rasterizer's float maps are bit-exact; torch-CPU float32
+restatements match the reference's torch-CPU float32 to <= 1e-5 abs (they run the same ATen kernels in a
+possibly different association order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster as oras
+from oracle import rnr_oracle as orc
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def T(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+@pytest.mark.parametrize('name', ['raster_soup64', 'raster_soup50', 'raster_soup64_nearfar', 'raster_sphere128'])
+def test_raster_c_bit_exact(golden, name):
+    g = golden(name)
+    r = oras.face_index_map(g['faces'], int(g['image_size']), float(g['near']), float(g['far']))
+    assert np.array_equal(r['face_index_map'], g['face_index_map'])
+    for k in ['faces_inv', 'weight_map', 'depth_map', 'face_inv_map']:
+        assert np.array_equal(bits(r[k]), bits(g[k])), k
+    cov = g['face_index_map'] >= 0
+    assert cov.any()
+    w = g['weight_map'][cov]
+    ok = np.isfinite(w).all(-1)
+    assert np.allclose(w[ok].sum(-1), 1.0, atol=1e-6)     # known-answer property
+
+
+def test_raster_texture_sampling_bit_exact(golden):
+    g = golden('raster_texsample32')
+    r = oras.texture_sampling(g['faces'], g['textures'], g['face_index_map'], g['weight_map'], g['depth_map'],
+                              int(g['image_size']), float(g['eps']))
+    assert np.array_equal(r['sampling_index_map'], g['sampling_index_map'])
+    assert np.array_equal(bits(r['rgb_map']), bits(g['rgb_map']))
+    assert np.array_equal(bits(r['sampling_weight_map']), bits(g['sampling_weight_map']))
+
+
+def test_projection(golden):
+    g = golden('projection')
+    a = orc.projection(T(g['vertices']), T(g['K']), T(g['R']), T(g['t']), torch.zeros(1, 5), int(g['orig_size']))
+    b = orc.projection(T(g['vertices']), T(g['K']), T(g['R']), T(g['t']), T(g['dist']), int(g['orig_size']),
+                       T(g['offset']), T(g['scale']))
+    assert torch.equal(a, T(g['out_nodist']))
+    assert torch.equal(b, T(g['out_dist']))
+
+
+def _mesh(g):
+    return {k: T(g['mesh_' + k]) for k in ['v', 'vt', 'vn', 'f_v_idx', 'f_vt_idx', 'f_vn_idx']}
+
+
+def test_rasterizer_module(golden):
+    g = golden('rasterizer_module64')
+    mesh = _mesh(g)
+    grt = T(g['global_RT'])
+    # network.py:126-128
+    v = torch.matmul(grt, torch.cat((mesh['v'], torch.ones(mesh['v'].shape[0], 1)), 1).t()).t()[:, :3]
+    vn = torch.nn.functional.normalize(torch.matmul(grt[:3, :3], mesh['vn'].t()).t(), dim=1)
+    assert torch.allclose(v, T(g['buf_vertices'])[0], atol=1e-6)
+    mesh['v'], mesh['vn'] = T(g['buf_vertices'])[0], T(g['buf_vertices_normals'])[0]
+    assert torch.allclose(vn, mesh['vn'], atol=1e-6)
+    for i in range(2):
+        out = orc.rasterizer_forward(mesh, T(g['proj'][i:i + 1]), T(g['pose'][i:i + 1]), int(g['image_size']))
+        assert torch.equal(out['face_index_map'], T(g['view%d_face_index_map' % i]))
+        assert torch.equal(out['alpha'], T(g['view%d_alpha' % i]))
+        assert torch.equal(out['v_front_mask'], T(g['view%d_v_front_mask' % i]))
+        assert torch.equal(out['faces_v_idx'], T(g['view%d_faces_v_idx' % i]))
+        for k in ['uv_map', 'weight_map', 'normal_map', 'normal_map_cam', 'faces_v', 'faces_vt', 'position_map',
+                  'position_map_cam', 'depth', 'v_uvz']:
+            ref = T(g['view%d_%s' % (i, k)])
+            assert out[k].shape == ref.shape, k
+            assert torch.allclose(out[k], ref, atol=2e-5, rtol=1e-5), (k, (out[k] - ref).abs().max())
+    assert (g['view0_alpha'] > 0).mean() > 0.2      # the sphere is actually visible (winding/cull sanity)
+
+
+def test_interpolate_bilinear(golden):
+    g = golden('bilinear')
+    out = orc.interpolate_bilinear(T(g['data']), T(g['x']), T(g['y']))
+    assert torch.allclose(out, T(g['out']), atol=1e-6)
+
+
+def test_texture_mapper(golden):
+    g = golden('texture_mapper')
+    tex = [T(g['tex%d' % i]) for i in range(4)]
+    assert torch.allclose(orc.texture_mapper(tex, T(g['uv']), T(g['sh']), 6), T(g['out_sh6']), atol=1e-6)
+    assert torch.allclose(orc.texture_mapper(tex, T(g['uv']), T(g['sh']), 3), T(g['out_sh3']), atol=1e-6)
+    assert torch.allclose(orc.texture_mapper(tex, T(g['uv']), None), T(g['out_nosh']), atol=1e-6)
+
+
+def test_shading_geometry(golden):
+    g = golden('shading_geometry64')
+    tbn = orc.tbn_map(T(g['normal_map']), T(g['face_index_map']), T(g['faces_v'])[0], T(g['faces_vt'])[0])
+    assert torch.allclose(tbn, T(g['tbn']), atol=1e-6)
+    vd, vdc = orc.view_dir_map((64, 64), T(g['proj_inv']), T(g['R_inv']))
+    assert torch.allclose(vd, T(g['view_dir']), atol=1e-6)
+    assert torch.allclose(vdc, T(g['view_dir_cam']), atol=1e-6)
+    Rs, piv = orc.ray_sampler_pivots(6, 2, 5)
+    assert torch.allclose(Rs, T(g['Rs_spec']), atol=1e-7) and torch.allclose(piv, T(g['pivots_spec']), atol=1e-7)
+    Rd, pivd = orc.ray_sampler_pivots(6, 2, 10)
+    assert torch.allclose(Rd, T(g['Rs_diff']), atol=1e-7) and torch.allclose(pivd, T(g['pivots_diff']), atol=1e-7)
+    alpha = T(g['alpha'])[..., None]
+    vt = T(g['view_tangent'])
+    d, uv, dt = orc.ray_sampler('reflect', piv, T(g['tbn']), vt, alpha)
+    assert torch.allclose(d, T(g['rays_dir_spec']), atol=2e-6)
+    assert torch.allclose(uv, T(g['rays_uv_spec']), atol=2e-6)
+    assert torch.allclose(dt, T(g['rays_dir_tangent_spec']), atol=2e-6)
+    d, uv, _ = orc.ray_sampler('diffuse', pivd, T(g['tbn']), vt, alpha)
+    assert torch.allclose(d, T(g['rays_dir_diff']), atol=2e-6)
+    assert torch.allclose(uv, T(g['rays_uv_diff']), atol=2e-6)
+    assert torch.allclose(orc.spherical_mapping(T(g['sm_dirs'])), T(g['sm_uv']), atol=1e-7)
+    assert torch.allclose(orc.spherical_mapping_inv(T(g['sm_inv_uv'])), T(g['sm_inv_dirs']), atol=1e-7)
+
+
+def _sd(g):
+    return {k[3:]: T(g[k]) for k in g.files if k.startswith('sd:')}
+
+
+def test_unet(golden):
+    g = golden('unet_nf4')
+    y = orc.unet_forward(_sd(g), T(g['x']))
+    assert torch.allclose(y, T(g['y']), atol=2e-5), (y - T(g['y'])).abs().max()
+    g = golden('unet_dnr_nf4')
+    y = orc.unet_forward(_sd(g), T(g['x']))
+    assert torch.allclose(y, T(g['y']), atol=2e-5)
+
+
+def test_ray_renderer(golden):
+    g = golden('ray_renderer')
+    out = orc.ray_renderer(T(g['albedo_specular']), T(g['rays_uv']), T(g['rays_lt']), T(g['lp']),
+                           albedo_diffuse=T(g['albedo_diffuse']), num_ray_diffuse=13, seperate_albedo=True)
+    for a, k in zip(out, ['out', 'out_specular', 'out_diffuse', 'ltt_specular', 'ltt_diffuse', 'rays_color']):
+        assert torch.allclose(a, T(g[k]), atol=2e-6), k
+    out = orc.ray_renderer(T(g['albedo_specular']), T(g['rays_uv']), T(g['rays_lt']), T(g['lp']))
+    assert torch.allclose(out[0], T(g['out_nodiffuse']), atol=2e-6)
+
+
+def test_sh_linear(golden):
+    g = golden('sh_linear')
+    assert torch.allclose(orc.reconstruct_sh(T(g['coeff']), T(g['basis'])), T(g['recon3']), atol=1e-5)
+    assert torch.allclose(orc.reconstruct_sh(T(g['coeff'])[0], T(g['basis'])), T(g['recon2']), atol=1e-5)
+    assert torch.allclose(orc.fit_sh_coeff(T(g['samples']), T(g['basis'])), T(g['fit3']), atol=1e-5)
+    assert torch.allclose(orc.fit_sh_coeff(T(g['samples'])[0], T(g['basis'])), T(g['fit2']), atol=1e-5)
+
+
+def test_sh_basis_independent_checks():
+    """sh_basis is PARITY-UNPINNED vs pyshtools; check it against scipy's complex harmonics with the
+    Condon-Shortley factor removed, the closed-form lmax = 2 table and the quadrature
+    orthonormality the reference relies on (sph_harm.py:80-86)."""
+    from scipy.special import sph_harm_y
+    from rnr_amd import scene
+    d = scene.sphere_samples(4096).astype(np.float64)
+    B = orc.sh_basis(10, d)
+    G = 4 * np.pi / d.shape[0] * B.T.dot(B)
+    assert np.abs(G - np.eye(121)).max() < 5e-3
+    theta = np.arctan2(np.hypot(d[:, 0], d[:, 1]), d[:, 2])
+    phi = np.arctan2(d[:, 1], d[:, 0])
+    col = 0
+    for l in range(11):
+        for m in range(-l, l + 1):
+            y = sph_harm_y(l, abs(m), theta, phi)
+            cs = (-1.0) ** abs(m)
+            ref = y.real if m == 0 else (np.sqrt(2) * cs * (y.real if m > 0 else y.imag))
+            assert np.abs(B[:, col] - ref).max() < 1e-9, (l, m)
+            col += 1
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    table = np.stack([0.2820948 + 0 * x, 0.4886025 * y, 0.4886025 * z, 0.4886025 * x, 1.0925484 * x * y,
+                      1.0925484 * y * z, 0.3153916 * (3 * z * z - 1), 1.0925484 * x * z,
+                      0.5462742 * (x * x - y * y)], -1)
+    dn = d / np.linalg.norm(d, axis=1, keepdims=True)
+    assert np.abs(B[:, :9] - table).max() < 1e-6
+
+
+def test_frame_assembly(golden):
+    """test_rnr.py:303-377 end to end (channel order of the network input, rays_lt scaling, albedo slices)."""
+    g = golden('frame64')
+    gm = golden('rasterizer_module64')
+    mesh = _mesh(gm)
+    mesh['v'], mesh['vn'] = T(gm['buf_vertices'])[0], T(gm['buf_vertices_normals'])[0]
+    views = {k: T(gm[k]) for k in ['proj', 'pose', 'proj_inv', 'R_inv']}
+    tex = [T(g['tex%d' % i]) for i in range(4)]
+    _, ps = orc.ray_sampler_pivots(6, 2, 5)
+    _, pd = orc.ray_sampler_pivots(6, 2, 10)
+    out = orc.render_frame(mesh, views, 64, tex, _sd(g), T(g['lp']), ps, pd)
+    assert torch.allclose(out['sh_basis_map'], T(g['sh_basis_map']), atol=1e-6)
+    assert torch.allclose(out['net_in'], T(g['net_in']).float(), atol=2e-3)       # stored as fp16
+    assert torch.allclose(out['unet_out'], T(g['net_out']).float(), atol=2e-3)
+    assert torch.allclose(out['image'], T(g['image']), atol=5e-5), (out['image'] - T(g['image'])).abs().max()
+    assert orc.psnr(out['image'], T(g['image'])) > 80
