@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py — rendered frames/s of the RNR deferred-render hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the full HIP hot path (projection -> rasterize -> shade inputs -> U-Net -> ray render) over
+one batch of `--views-per-step` synthetic 512x512 camera poses of the material_sphere-like scene,
+inputs resident in HBM.  `value` = views rendered by ALL ranks / max-over-ranks wall time of exactly K steps.
+
+Single GPU:  python bench.py [--steps K --warmup W]
+N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+             bench.py --gpus N --steps K --warmup W       (weak scaling: every rank renders its own pose slice and the
+             frames are all-gathered over RCCL each step — the only collective of the path)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'relightable-nr_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (f32 in / f32 acc)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--views-per-step', type=int, default=4, help='camera poses per GPU per step')
+    ap.add_argument('--img-size', type=int, default=512)
+    ap.add_argument('--nf0', type=int, default=64)
+    ap.add_argument('--tex-ch', type=int, default=24)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    return ap.parse_args()
+
+
+def build_scene(args):
+    from rnr_amd import scene, testing
+    ps, pd = testing.ray_pivots(6, 2, 5), testing.ray_pivots(6, 2, 10)       # train_rnr.py:344-354 defaults
+    n_rays = ps.shape[1] + pd.shape[1]
+    c_in = 3 * n_rays + 6 + args.tex_ch
+    return {
+        'mesh': scene.uv_sphere(128, 256),                                    # 65 536 faces
+        'textures': testing.synthetic_textures(512, args.tex_ch, 4, 0),
+        'unet_sd': testing.unet_state_dict(c_in, 3 * n_rays, args.nf0, 5, 0),
+        'pivots_spec': ps, 'pivots_diff': pd,
+        'lp': testing.synthetic_light_probe(100, 200, 2),
+        'c_in': c_in, 'n_rays': n_rays,
+    }
+
+
+def cpu_baseline(sc, args, view_id, hip_image):
+    """The oracle (a port of the reference's algorithm) timed on this box's host cores on ONE frame of the same
+    workload; also yields the parity figure (PSNR of the HIP frame vs the oracle frame)."""
+    from oracle import rnr_oracle as orc
+    from oracle import raster as oras
+    from rnr_amd import scene
+    oras.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    views = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [view_id]).items()}
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    t0 = time.time()
+    ref = orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'],
+                           sc['pivots_diff'])
+    dt = time.time() - t0
+    out = {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+           'sample': '1 frame %dx%d, same scene/weights (oracle: OpenMP C rasterizer + torch-CPU fp32 shading/U-Net), %.1f s'
+                     % (args.img_size, args.img_size, dt)}
+    parity = None
+    if hip_image is not None:
+        parity = {'psnr_db_vs_oracle': orc.psnr(hip_image.cpu(), ref['image']),
+                  'max_abs_err': float((hip_image.cpu() - ref['image']).abs().max())}
+    return out, parity
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)       # "nccl" is RCCL on ROCm
+    from rnr_amd import scene
+    from rnr_amd.pipeline import RNRPipeline
+    sc = build_scene(args)
+    V = args.views_per_step
+    pipe = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'],
+                       sc['lp'], nf0=args.nf0, max_views=V, device=dev)
+    # pose slices: step s, rank r renders spiral views (s*world + r)*V ... +V  (mod 720)
+    n_total = (args.steps + args.warmup) * world * V
+    ids = (np.arange(n_total) * 7) % 720
+    allv = scene.spiral_views(args.img_size, ids)
+    poses = {k: torch.from_numpy(v).to(dev) for k, v in allv.items()}
+    gathered = torch.empty(world * V, 3, args.img_size, args.img_size, device=dev) if world > 1 else None
+
+    def step(s):
+        lo = (s * world + rank) * V
+        sl = slice(lo, lo + V)
+        img = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, img)       # frames over xGMI; the only exchange of the path
+        return img
+
+    for s in range(args.warmup):
+        step(s)
+    # ---- per-stage HIP-event timing of the dominant stage (U-Net convs) on the launch stream ----
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    orig_forward = pipe.unet.forward
+
+    def timed_forward(net_in, n_views=None, _i=[0]):
+        ev[2 * _i[0]].record()
+        r = orig_forward(net_in, n_views)
+        ev[2 * _i[0] + 1].record()
+        _i[0] += 1
+        return r
+    pipe.unet.forward = timed_forward
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        img = step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pipe.unet.forward = orig_forward
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    unet_ms = float(np.mean([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)]))
+    flops_step = pipe.unet.flops_per_view * V
+    n_conv = len(pipe.unet.steps)
+    achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        res = {
+            'metric': 'rendered frames/sec at %dx%d (material_sphere-like synthetic scene), full HIP RNR path'
+                      % (args.img_size, args.img_size),
+            'value': args.steps * world * V / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: test_rnr.py spiral_step720 views, %dx%d, full HIP RenderingNet '
+                                   '(f32 MFMA convs + SH relight), UV-sphere 65536 faces, neural texture 512^2 x %d ch x 4 '
+                                   'levels, U-Net %d->%d nf0=%d' % (args.img_size, args.img_size, args.tex_ch, sc['c_in'],
+                                                                   3 * sc['n_rays'], args.nf0),
+                       'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (%d launches/step, U-Net stage incl. bn_finalize)' % n_conv,
+                         'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            last_id = int(ids[(args.warmup + args.steps - 1) * V + V - 1])
+            hip_last = None if args.no_parity else img[V - 1:V]
+            cb, parity = cpu_baseline(sc, args, last_id, hip_last)
+            res['cpu_baseline'] = cb
+            if parity:
+                res['parity'] = parity
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,248 @@
+/*
+ * rnr_hip.h — C ABI of librnr_hip.so: the MI355X (gfx950) implementation of the deferred-render hot path
+ * of LansburyCH/relightable-nr (rasterize -> neural-texture sample -> SH basis -> RenderingNet U-Net ->
+ * ray render).  Plain pointers and sizes only; no torch / ATen types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`;
+ *   - tensors are dense, row-major, float32 / int32, in the layouts written next to each argument;
+ *   - the CALLER allocates every output (and pre-fills it where the reference does, see each function);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what the
+ *     reference's <<<blocks, threads>>> launches use, rasterize_cuda_kernel.cu:615,629,670);
+ *   - return value: 0 = success; non-zero = error, message available from rnr_last_error().
+ *     Unlike the reference (which only printf()s kernel-launch failures, rasterize_cuda_kernel.cu:623-625)
+ *     every launch is checked with hipGetLastError() and reported.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef RNR_HIP_H
+#define RNR_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNR_ABI_VERSION 1
+
+int rnr_abi_version(void);
+/* Thread-local, NUL-terminated description of the last failing call on this thread ("" if none). */
+const char* rnr_last_error(void);
+
+/* =====================================================================================================
+ * 1. neural_renderer.cuda.rasterize — drop-in for the pybind module (rasterize_cuda.cpp:124-191)
+ * ===================================================================================================== */
+
+/* Bytes of scratch rnr_forward_face_index_map needs for (batch, num_faces). */
+size_t rnr_raster_workspace_bytes(int batch_size, int num_faces);
+
+/*
+ * forward_face_index_map (rasterize_cuda.cpp:66-98 -> rasterize_cuda_kernel.cu:24-169, launch 595-650).
+ *   faces          [B, nf, 3, 3]  (x_ndc, y_ndc, z_cam) per vertex
+ *   face_index_map [B, is, is]    int32, caller pre-fills -1      (rasterize.py:50)
+ *   weight_map     [B, is, is, 3] caller pre-fills 0              (rasterize.py:51)
+ *   depth_map      [B, is, is]    caller pre-fills `far`          (rasterize.py:52)
+ *   face_inv_map   [B, is, is, 3, 3] written when return_depth != 0 (may be NULL otherwise)
+ *   faces_inv      [B, nf, 3, 3]  caller pre-fills 0              (rasterize.py:163)
+ *   workspace      rnr_raster_workspace_bytes(B, nf) bytes of device scratch
+ * Rows are in the extension's native order (row 0 = bottom of the image); the vertical flip is done by the
+ * Python layer (rasterize.py:307-321).  Only covered pixels are written.  Results are bit-identical to the
+ * reference kernels evaluated in IEEE binary32 without FMA contraction.
+ */
+int rnr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
+                               float* depth_map, float* face_inv_map, float* faces_inv,
+                               int batch_size, int num_faces, int image_size, float near_, float far_,
+                               int return_rgb, int return_alpha, int return_depth,
+                               void* workspace, void* stream);
+
+/*
+ * forward_texture_sampling (rasterize_cuda.cpp:100-122 -> rasterize_cuda_kernel.cu:171-242, launch 652-691).
+ *   textures [B, nf, ts, ts, ts, 3]; rgb_map [B, is, is, 3]; sampling_index_map [B, is, is, 8] int32;
+ *   sampling_weight_map [B, is, is, 8].  Only covered pixels are written.
+ */
+int rnr_forward_texture_sampling(const float* faces, const float* textures, const int32_t* face_index_map,
+                                 const float* weight_map, const float* depth_map, float* rgb_map,
+                                 int32_t* sampling_index_map, float* sampling_weight_map,
+                                 int batch_size, int num_faces, int image_size, int texture_size, float eps,
+                                 void* stream);
+
+/* =====================================================================================================
+ * 2. Fused hot path (one view batch = N camera poses of one mesh)
+ * ===================================================================================================== */
+
+/*
+ * nr.projection (neural_renderer/projection.py:6-53) for a shared mesh.
+ *   vertices [nv, 3] world; K [N,3,3]; R [N,3,3]; t [N,3]; dist_coeffs [N,5] or NULL (= zeros);
+ *   offset/scale [N,2] or both NULL; out [N, nv, 3] = (u_ndc, v_ndc, z_cam).
+ */
+int rnr_project_vertices(const float* vertices, const float* K, const float* R, const float* t,
+                         const float* dist_coeffs, const float* offset, const float* scale,
+                         float* out, int num_views, int num_vertices, float orig_size, float eps,
+                         void* stream);
+
+/* Mesh description shared by the G-buffer kernels (all device pointers, int32 indices 0-based as produced
+ * by load_obj.py:176-178). */
+typedef struct rnr_mesh {
+    const float* v;          /* [nv, 3] world positions (global_RT applied, network.py:127) */
+    const float* vt;         /* [nvt, 2] */
+    const float* vn;         /* [nvn, 3] (global_RT applied + normalised, network.py:128) */
+    const int32_t* f_v_idx;  /* [nf, 3] */
+    const int32_t* f_vt_idx; /* [nf, 3] */
+    const int32_t* f_vn_idx; /* [nf, 3] */
+    int num_vertices, num_texcoords, num_normals, num_faces;
+} rnr_mesh;
+
+/* Outputs of network.Rasterizer.forward (network.py:156-216) that are per-pixel maps; any pointer may be
+ * NULL to skip that map.  Rows are already flipped (row 0 = top), as rasterize_rgbad returns them. */
+typedef struct rnr_gbuffer {
+    int32_t* face_index_map; /* [N,S,S]   -1 = background */
+    float* alpha;            /* [N,S,S]   {0,1} */
+    float* depth;            /* [N,S,S]   far on background */
+    float* weight_map;       /* [N,S,S,3] perspective-corrected w'_k = w_k * depth / z_k (network.py:176-180) */
+    float* raw_weight_map;   /* [N,S,S,3] the kernel's clamped+renormalised barycentrics */
+    float* uv_map;           /* [N,S,S,2] wrapped to [0,1) (network.py:187-190) */
+    float* normal_map;       /* [N,S,S,3] */
+    float* normal_map_cam;   /* [N,S,S,3] */
+    float* position_map;     /* [N,S,S,3] */
+    float* position_map_cam; /* [N,S,S,3] */
+} rnr_gbuffer;
+
+size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces);
+
+/*
+ * projected vertices -> per-face setup -> tiled z-resolve -> attribute interpolation, i.e.
+ * renderer.py:244-257 + rasterize.py:255-340 + network.py:156-214 in one pass (no texture kernel: the hot
+ * path feeds it an all-zero texture and discards rgb, network.py:140-142,157).
+ *   v_uvz [N, nv, 3] from rnr_project_vertices; pose [N,4,4] (for the *_cam maps; may be NULL if unused).
+ */
+int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, const float* pose, int num_views,
+                          int image_size, float near_, float far_, const rnr_gbuffer* out,
+                          void* workspace, void* stream);
+
+/* Per-face unit tangents of render.get_TBN_map (render.py:135-150); static per mesh.  out [nf,3]. */
+int rnr_face_tangents(const rnr_mesh* mesh, float* out, void* stream);
+
+/* Ray-sampler constants (network.RaySampler buffers `pivots_dir`, network.py:441-443), HOST pointers. */
+typedef struct rnr_rays {
+    const float* pivots_spec_host; /* [3, num_spec] */
+    const float* pivots_diff_host; /* [3, num_diff] */
+    int num_spec, num_diff;        /* <= 32 each */
+} rnr_rays;
+
+/*
+ * G-buffer -> RenderingNet input, fusing render.get_TBN_map (render.py:152-166), camera.get_view_dir_map
+ * (camera.py:5-32), the tangent-space view direction (test_rnr.py:314-315), the lmax=2 SH basis
+ * (sph_harm.py:41-71), TextureMapper.forward (network.py:67-91 + misc.py:5-42), both RaySamplers
+ * (network.py:445-472) and the channel assembly of test_rnr.py:349-356.
+ *   textures[level] [S_l, S_l, C] (level sizes tex_sizes_host[level]); num_levels <= 8
+ *   net_in  [N, H, W, Cpad] channel-last; channel order 3*(num_spec+num_diff) ray dirs (ray-major), normal (3),
+ *           view_dir (3), neural texture (C); channels >= Cin are zero-filled
+ *   rays_uv [N, H, W, 2, num_spec+num_diff] or NULL; neural_img [N, C, H, W] or NULL (API copies)
+ *   sh_basis_map [N,H,W,9] or NULL (written when non-NULL)
+ */
+int rnr_shade_inputs(const int32_t* face_index_map, const float* alpha, const float* uv_map,
+                     const float* normal_map, const float* face_tangents, int num_faces,
+                     const float* proj_inv, const float* R_inv,
+                     const float* const* textures_host, const int* tex_sizes_host, int num_levels,
+                     int tex_channels, int sh_start_ch, const rnr_rays* rays,
+                     float* net_in, int c_pad, float* rays_uv, float* neural_img, float* sh_basis_map,
+                     int num_views, int height, int width, void* stream);
+
+/* ---- U-Net convolution stack (pytorch_prototyping.py:96-277, 370-536), channel-last activations ---- */
+
+enum { RNR_ACT_NONE = 0, RNR_ACT_LRELU02 = 1, RNR_ACT_RELU = 2 };
+enum { RNR_CONV3x3_REFLECT = 0, RNR_CONV4x4S2_REFLECT = 1, RNR_CONVT4x4S2 = 2 };
+
+/* One input source of a convolution: a raw (pre-normalisation) channel-last tensor plus the per-view,
+ * per-channel affine + activation the producer's BatchNorm/bias/activation implies:
+ *     value(n,h,w,c) = act(scale[n,c] * raw[n,h,w,c] + shift[n,c]).
+ * scale/shift NULL = identity.  Two sources = torch.cat([src0, src1], 1) (pytorch_prototyping.py:429). */
+typedef struct rnr_conv_src {
+    const float* data;  /* [N, H, W, channels] */
+    const float* scale; /* [N, channels] or NULL */
+    const float* shift; /* [N, channels] or NULL */
+    int channels;       /* multiple of 4 */
+    int act;            /* RNR_ACT_* */
+} rnr_conv_src;
+
+/* Static description of one convolution of the U-Net.  Channel counts `*_pad` are the channel strides of the
+ * channel-last tensors (multiples of 16; padding channels hold zeros / meet zero weights). */
+typedef struct rnr_conv_desc {
+    int kind;                 /* RNR_CONV3x3_REFLECT | RNR_CONV4x4S2_REFLECT | RNR_CONVT4x4S2 */
+    int c_in0, c_in0_pad;     /* first source: live channels, channel stride */
+    int c_in1, c_in1_pad;     /* second source of a skip concat (0, 0 if none) */
+    int c_out, c_out_pad;     /* live output channels, channel stride of out_raw (multiple of 16) */
+} rnr_conv_desc;
+
+/* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
+size_t rnr_packed_weight_floats(const rnr_conv_desc* d);
+/* PyTorch layout -> packed.  Conv2d weight [c_out, c_in0 + c_in1, kh, kw] (pytorch_prototyping.py:116, 250-268);
+ * ConvTranspose2d weight [c_in0 + c_in1, c_out, 4, 4] (pytorch_prototyping.py:154-159). */
+int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream);
+
+/* Scratch bytes rnr_conv2d may need for (desc, N, input H, input W) (split-K partial slabs). */
+size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views, int in_h, int in_w);
+
+/*
+ * out_raw[n,ho,wo,co] = sum_{taps,ci} value(src)[...] * weight  (no bias: it is folded into the consumer's
+ * `shift`, or applied by rnr_ray_render / rnr_nhwc_to_nchw for the last layer).  When stats != NULL the call
+ * also zeroes and then accumulates per-view, per-channel sum / sum-of-squares of out_raw into
+ * stats [N, c_out_pad, 2] (float64), for the batch-statistics BatchNorm the reference runs at inference
+ * (test_rnr.py:229-233).
+ *   src0/src1: `channels` must equal c_in0_pad / c_in1_pad; src1 may be NULL when c_in1_pad == 0.
+ *   out_raw [N, Ho, Wo, c_out_pad]  (Ho,Wo = H,W | H/2,W/2 | 2H,2W by kind)
+ */
+int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+               const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h, int in_w,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* stats [N,c_pad,2] (sum, sumsq over `count` pixels) + gamma/beta [channels] -> scale/shift [N,c_pad]:
+ * scale = gamma / sqrt(var_biased + eps), shift = beta - mean * scale  (BatchNorm2d in train mode: per-view
+ * batch statistics, biased variance); channels >= `channels` get scale = shift = 0. */
+int rnr_bn_finalize(const double* stats, const float* gamma, const float* beta, float* scale, float* shift,
+                    int num_views, int channels, int c_pad, double count, float eps, void* stream);
+
+/* Layout helpers for the drop-in RenderingNet.forward (NCHW in / NCHW out). */
+int rnr_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream);
+/* out[n,c,h,w] = f(in[n,h,w,c] + bias[c]) with bias optional (NULL) and f = tanhf when apply_tanh != 0 */
+int rnr_nhwc_to_nchw(const float* in, float* out, const float* bias, int apply_tanh,
+                     int n, int c, int h, int w, int c_pad, void* stream);
+
+/*
+ * Last stage of a frame: out-layer bias + tanh (network.py:253), rays_lt = (y*0.5+0.5)*2
+ * (test_rnr.py:357-359) and RayRenderer.forward (network.py:481-527) with seperate_albedo=True:
+ * equirect uv of every ray from the ray directions stored in net_in, bilinear env-map taps
+ * (network.py:497 + misc.py:5-42), light-transport weighted sums / num rays, times the albedos.
+ *   unet_raw [N,H,W,c_out_pad] raw output of the out-layer conv (78 live channels, ray-major RGB)
+ *   bias [3*(num_spec+num_diff)]; net_in as written by rnr_shade_inputs; alpha [N,H,W]
+ *   lp [Hl, Wl, 3] environment map (LightingSH.reconstruct_lp, network.py:622-627)
+ *   image [N,3,H,W]
+ */
+int rnr_ray_render(const float* unet_raw, int c_out_pad, const float* bias, const float* net_in, int c_pad,
+                   const float* alpha, const float* lp, int lp_h, int lp_w, int num_spec, int num_diff,
+                   int albedo_diff_ch, int albedo_spec_ch, float* image, int num_views, int height,
+                   int width, void* stream);
+
+/* ---- spherical harmonics (sph_harm.py:41-102) ---- */
+
+/* Real orthonormal SH without Condon-Shortley phase, columns (l, m=-l..l); dirs [n,3] (need not be unit),
+ * out [n, (lmax+1)^2].  lmax <= 16. */
+int rnr_sh_basis(const float* dirs, float* out, int n, int lmax, void* stream);
+/* out[s, c] = sum_b basis[s,b] * coeff[b,c]  (sph_harm.reconstruct_sh, sph_harm.py:91-102) */
+int rnr_sh_reconstruct(const float* basis, const float* coeff, float* out, int num_samples, int num_basis,
+                       int num_channels, void* stream);
+/* out[b, c] = 4pi/num_samples * sum_s samples[s,c] * basis[s,b]  (sph_harm.fit_sh_coeff, sph_harm.py:74-88) */
+int rnr_sh_fit(const float* samples, const float* basis, float* out, int num_samples, int num_basis,
+               int num_channels, void* stream);
+
+/* misc.interpolate_bilinear (misc.py:5-42): data [H,W,C], x/y [n] -> out [n,C]; optional tap index output
+ * taps [n,4] int32 = (x0,y0,x1,y1) fetch indices (bit-exact integer part of the sampler). */
+int rnr_interpolate_bilinear(const float* data, int h, int w, int c, const float* x, const float* y,
+                             float* out, int32_t* taps, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNR_HIP_H */

@@ -1,0 +1,549 @@
+// RenderingNet U-Net convolutions as implicit GEMMs on the gfx950 matrix cores, exact fp32
+// (v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bitwise an fmaf chain; peak 157.3 TFLOP/s).
+//
+// Covers every conv of pytorch_prototyping.py on the live path:
+//   KIND 0  ReflectionPad2d(1) + Conv2d 3x3 s1     Conv2dSame (pytorch_prototyping.py:96-121), DownBlock prep conv (239-246)
+//   KIND 1  ReflectionPad2d(1) + Conv2d 4x4 s2     DownBlock (258-264)
+//   KIND 2  ConvTranspose2d 4x4 s2 p1              UpBlock (154-159), as four 2x2-tap parity classes
+//
+// GEMM view: rows = output pixels (n, oy, ox), columns = output channels, K = taps x input channels.
+// Activations are channel-last, so a K-chunk of 16 channels of one tap is 64 contiguous bytes per pixel.
+// What is fused here instead of being separate passes (the reference runs conv, BatchNorm, activation,
+// ReflectionPad and torch.cat as separate kernels with full-tensor round trips):
+//   * prologue  : value = act(scale[n,c] * raw + shift[n,c]) — the producer's train-mode BatchNorm (+ bias)
+//                 and (Leaky)ReLU applied while the A operand is staged; reflection padding and the skip
+//                 concat are pure index arithmetic on the gather;
+//   * epilogue  : per-view per-channel sum / sum-of-squares of the raw output (wave shuffles -> LDS ->
+//                 one fp64 atomic per channel per workgroup) for the next BatchNorm's batch statistics.
+#include "rnr_internal.h"
+
+namespace rnr {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int CTHREADS = 256;
+
+struct ConvParams {
+    const float* src_data[2];
+    const float* src_scale[2];
+    const float* src_shift[2];
+    int src_c[2];
+    int src_act[2];
+    const float* weight;
+    float* out;
+    double* stats;
+    int N, H, W;        // input spatial size
+    int Ho, Wo;         // GEMM row space per view (conv: output size; convT: input size, per parity class)
+    int OH, OW;         // true output size
+    int M;              // GEMM rows (per parity class)
+    int c_out, c_out_pad;
+    int chunks0, chunks_per_tap, kt_total;
+    int splitk;
+    long slab_stride;   // floats between split-K slabs
+};
+
+__device__ __forceinline__ int reflect1(int i, int n) {   // ReflectionPad2d(1)
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == RNR_ACT_LRELU02) return v > 0.0f ? v : 0.2f * v;
+    if (act == RNR_ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(CTHREADS)
+conv_mfma_kernel(const ConvParams P) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int RPT = BM / 64;
+    constexpr int BQ = BK * BN / 4;                       // float4 slots of a B tile
+    constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
+    constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
+    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int wm0 = wave_m * WM * 32, wn0 = wave_n * WN * 32;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int par = (KIND == 2) ? (int)(blockIdx.z & 3) : 0;
+    const int split = (KIND == 2) ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    const int py = par >> 1, px = par & 1;
+    const int hw_rows = P.Ho * P.Wo;
+
+    // ---- the rows this thread stages (fixed for the whole K loop) ----
+    const int q = tid & 3;
+    int rn[RPT], roy[RPT], rox[RPT];
+    bool rvalid[RPT];
+#pragma unroll
+    for (int p = 0; p < RPT; p++) {
+        const int m = m0 + (tid >> 2) + 64 * p;
+        rvalid[p] = m < P.M;
+        const int mm = rvalid[p] ? m : 0;
+        rn[p] = mm / hw_rows;
+        const int rem = mm - rn[p] * hw_rows;
+        roy[p] = rem / P.Wo;
+        rox[p] = rem - roy[p] * P.Wo;
+    }
+    const int m_last = min(m0 + BM, P.M) - 1;
+    const bool single_view = (m0 / hw_rows) == (m_last / hw_rows);
+    const int n_tile = m0 / hw_rows;
+
+    const int per_split = (P.kt_total + P.splitk - 1) / P.splitk;
+    const int kt0 = split * per_split;
+    const int kt1 = min(P.kt_total, kt0 + per_split);
+
+    float4 areg[RPT];
+    float4 breg[BPT];
+
+    auto load_regs = [&](int kt) {
+        const int tp = kt / P.chunks_per_tap;
+        const int ch = kt - tp * P.chunks_per_tap;
+        const int s = ch < P.chunks0 ? 0 : 1;
+        const int cc = (ch - (s ? P.chunks0 : 0)) * BK + 4 * q;
+        const int C = P.src_c[s];
+        const float* data = P.src_data[s];
+        const float* scp = P.src_scale[s];
+        const float* shp = P.src_shift[s];
+        const int act = P.src_act[s];
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (single_view) {
+            if (scp) sc = *reinterpret_cast<const float4*>(scp + (size_t)n_tile * C + cc);
+            if (shp) sh = *reinterpret_cast<const float4*>(shp + (size_t)n_tile * C + cc);
+        }
+#pragma unroll
+        for (int p = 0; p < RPT; p++) {
+            int iy, ix;
+            bool ok = rvalid[p];
+            if (KIND == 0) {
+                iy = reflect1(roy[p] + tp / 3 - 1, P.H);
+                ix = reflect1(rox[p] + tp % 3 - 1, P.W);
+            } else if (KIND == 1) {
+                iy = reflect1(2 * roy[p] + (tp >> 2) - 1, P.H);
+                ix = reflect1(2 * rox[p] + (tp & 3) - 1, P.W);
+            } else {
+                // out(2a+py) = sum over ky with iy = (oy + 1 - ky)/2: py=0 -> (ky=1, iy=a), (ky=3, iy=a-1);
+                //                                                     py=1 -> (ky=0, iy=a+1), (ky=2, iy=a)
+                const int ty = tp >> 1, tx = tp & 1;
+                iy = roy[p] + (py == 0 ? (ty == 0 ? 0 : -1) : (ty == 0 ? 1 : 0));
+                ix = rox[p] + (px == 0 ? (tx == 0 ? 0 : -1) : (tx == 0 ? 1 : 0));
+                ok = ok && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const size_t pidx = ((size_t)rn[p] * P.H + iy) * P.W + ix;
+                v = *reinterpret_cast<const float4*>(data + pidx * C + cc);
+                if (!single_view) {
+                    if (scp) sc = *reinterpret_cast<const float4*>(scp + (size_t)rn[p] * C + cc);
+                    if (shp) sh = *reinterpret_cast<const float4*>(shp + (size_t)rn[p] * C + cc);
+                }
+                v.x = apply_act(v.x * sc.x + sh.x, act);
+                v.y = apply_act(v.y * sc.y + sh.y, act);
+                v.z = apply_act(v.z * sc.z + sh.z, act);
+                v.w = apply_act(v.w * sc.w + sh.w, act);
+            }
+            areg[p] = v;
+        }
+        const size_t krow0 = ((size_t)(par * TAPS + tp) * P.chunks_per_tap + ch) * BK;
+#pragma unroll
+        for (int b = 0; b < BPT; b++) {
+            const int idx = tid + CTHREADS * b;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < BQ) {
+                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
+                const int col = n0 + 4 * c4;
+                if (col < P.c_out_pad) w = *reinterpret_cast<const float4*>(P.weight + (krow0 + kr) * P.c_out_pad + col);
+            }
+            breg[b] = w;
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < RPT; p++) {
+            const int r = (tid >> 2) + 64 * p;
+            float* a = &As[buf][(4 * q) * LDA + r];
+            a[0 * LDA] = areg[p].x;
+            a[1 * LDA] = areg[p].y;
+            a[2 * LDA] = areg[p].z;
+            a[3 * LDA] = areg[p].w;
+        }
+#pragma unroll
+        for (int b = 0; b < BPT; b++) {
+            const int idx = tid + CTHREADS * b;
+            if (idx < BQ) {
+                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[buf][kr * LDB + 4 * c4]) = breg[b];
+            }
+        }
+    };
+
+    floatx16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+
+    if (kt0 < kt1) {
+        load_regs(kt0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt++) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) load_regs(kt + 1);
+        const float* a_s = &As[buf][wm0 + l31];
+        const float* b_s = &Bs[buf][wn0 + l31];
+#pragma unroll
+        for (int s = 0; s < BK / 2; s++) {
+            const int k = 2 * s + h;
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; i++) a[i] = a_s[k * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; j++) b[j] = b_s[k * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int j = 0; j < WN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: raw output (or split-K slab) ----
+    float* out = P.out + (size_t)split * P.slab_stride;
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int row = wm0 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int m = m0 + row;
+            if (m < P.M) {
+                size_t off;
+                if (KIND == 2) {
+                    const int n = m / hw_rows;
+                    const int rem = m - n * hw_rows;
+                    const int a = rem / P.Wo, b = rem - a * P.Wo;
+                    off = (((size_t)n * P.OH + 2 * a + py) * P.OW + 2 * b + px) * P.c_out_pad;
+                } else {
+                    off = (size_t)m * P.c_out_pad;
+                }
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int col = n0 + wn0 + 32 * j + l31;
+                    if (col < P.c_out_pad) out[off + col] = acc[i][j][g];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: batch statistics of the raw output ----
+    if (P.stats && P.splitk == 1) {
+        if (single_view) {
+            float* red = &As[0][0];   // [WAVES_M][BN][2], LDS is free after the last barrier
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < WM; i++)
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        const float v = acc[i][j][g];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    const int col = wn0 + 32 * j + l31;
+                    red[(wave_m * BN + col) * 2 + 0] = s1;
+                    red[(wave_m * BN + col) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                const int col = n0 + tid;
+                if (col < P.c_out) {
+                    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int w = 0; w < WAVES_M; w++) {
+                        s1 += (double)red[(w * BN + tid) * 2 + 0];
+                        s2 += (double)red[(w * BN + tid) * 2 + 1];
+                    }
+                    double* st = P.stats + ((size_t)n_tile * P.c_out_pad + col) * 2;
+                    atomicAdd(st + 0, s1);
+                    atomicAdd(st + 1, s2);
+                }
+            }
+        } else {   // tiles straddling views only occur for maps smaller than a tile (tiny layers)
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const int m = m0 + wm0 + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (m < P.M) {
+                        const int n = m / hw_rows;
+#pragma unroll
+                        for (int j = 0; j < WN; j++) {
+                            const int col = n0 + wn0 + 32 * j + l31;
+                            if (col < P.c_out) {
+                                const float v = acc[i][j][g];
+                                double* st = P.stats + ((size_t)n * P.c_out_pad + col) * 2;
+                                atomicAdd(st + 0, (double)v);
+                                atomicAdd(st + 1, (double)v * (double)v);
+                            }
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// out[m,c] = sum_s slab[s][m,c]; statistics per view.  grid (rows/64, c_out_pad/64), 256 threads.
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk, float* __restrict__ out,
+                     double* __restrict__ stats, long rows, int rows_per_view, int c_out, int c_out_pad) {
+    __shared__ float red[4][64][2];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cx;
+    const long r0 = (long)blockIdx.x * 64;
+    const bool single_view = (r0 / rows_per_view) == ((min(r0 + 64, rows) - 1) / rows_per_view);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = ry; r < 64; r += 4) {
+        const long m = r0 + r;
+        if (m < rows && col < c_out_pad) {
+            float v = 0.f;
+            for (int s = 0; s < splitk; s++) v += slabs[(size_t)s * slab_stride + (size_t)m * c_out_pad + col];
+            out[(size_t)m * c_out_pad + col] = v;
+            if (stats && col < c_out) {
+                if (single_view) { s1 += v; s2 += v * v; }
+                else {
+                    double* st = stats + ((size_t)(m / rows_per_view) * c_out_pad + col) * 2;
+                    atomicAdd(st + 0, (double)v);
+                    atomicAdd(st + 1, (double)v * (double)v);
+                }
+            }
+        }
+    }
+    if (!stats) return;
+    red[ry][cx][0] = s1;
+    red[ry][cx][1] = s2;
+    __syncthreads();
+    if (single_view && ry == 0 && col < c_out) {
+        const double a = (double)red[0][cx][0] + (double)red[1][cx][0] + (double)red[2][cx][0] + (double)red[3][cx][0];
+        const double b = (double)red[0][cx][1] + (double)red[1][cx][1] + (double)red[2][cx][1] + (double)red[3][cx][1];
+        double* st = stats + ((size_t)(r0 / rows_per_view) * c_out_pad + col) * 2;
+        atomicAdd(st + 0, a);
+        atomicAdd(st + 1, b);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                   float* __restrict__ scale, float* __restrict__ shift, int nviews, int channels, int c_pad,
+                   double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nviews * c_pad) return;
+    const int c = i % c_pad;
+    float sc = 0.f, sh = 0.f;
+    if (c < channels) {
+        const double mean = stats[2 * (size_t)i + 0] / count;
+        double var = stats[2 * (size_t)i + 1] / count - mean * mean;    // biased variance
+        var = var < 0.0 ? 0.0 : var;
+        const double s = (double)gamma[c] / sqrt(var + (double)eps);
+        sc = (float)s;
+        sh = (float)((double)beta[c] - mean * s);
+    }
+    scale[i] = sc;
+    shift[i] = sh;
+}
+
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restrict__ packed, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int taps = d.kind == RNR_CONV3x3_REFLECT ? 9 : (d.kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
+    const int ctot = d.c_in0_pad + d.c_in1_pad;
+    const int co = (int)(i % d.c_out_pad);
+    long r = i / d.c_out_pad;
+    const int c = (int)(r % ctot);
+    r /= ctot;
+    const int tp = (int)(r % taps);
+    const int par = (int)(r / taps);
+    int ci = -1;
+    if (c < d.c_in0_pad) { if (c < d.c_in0) ci = c; }
+    else { const int c1 = c - d.c_in0_pad; if (c1 < d.c_in1) ci = d.c_in0 + c1; }
+    float v = 0.0f;
+    if (ci >= 0 && co < d.c_out) {
+        const int cin = d.c_in0 + d.c_in1;
+        if (d.kind == RNR_CONV3x3_REFLECT) {
+            v = w[((size_t)co * cin + ci) * 9 + tp];
+        } else if (d.kind == RNR_CONV4x4S2_REFLECT) {
+            v = w[((size_t)co * cin + ci) * 16 + tp];
+        } else {
+            const int py = par >> 1, px = par & 1, ty = tp >> 1, tx = tp & 1;
+            const int ky = py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
+            const int kx = px == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+            v = w[((size_t)ci * d.c_out + co) * 16 + ky * 4 + kx];
+        }
+    }
+    packed[i] = v;
+}
+
+struct ConvPlan {
+    int cfg;        // 0: 256x64, 1: 256x96, 2: 128x128
+    int bm, bn, mtiles, ntiles, par, splitk;
+    int Ho, Wo, OH, OW, M;
+    int taps, chunks_per_tap, kt_total;
+};
+
+static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
+    p->taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : (d->kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
+    p->par = d->kind == RNR_CONVT4x4S2 ? 4 : 1;
+    if (d->kind == RNR_CONV3x3_REFLECT) { p->Ho = H; p->Wo = W; p->OH = H; p->OW = W; }
+    else if (d->kind == RNR_CONV4x4S2_REFLECT) { p->Ho = H / 2; p->Wo = W / 2; p->OH = H / 2; p->OW = W / 2; }
+    else { p->Ho = H; p->Wo = W; p->OH = 2 * H; p->OW = 2 * W; }
+    p->M = N * p->Ho * p->Wo;
+    p->chunks_per_tap = (d->c_in0_pad + d->c_in1_pad) / BK;
+    p->kt_total = p->taps * p->chunks_per_tap;
+    if (d->c_out_pad <= 64) { p->cfg = 0; p->bm = 256; p->bn = 64; }
+    else if (d->c_out_pad <= 96) { p->cfg = 1; p->bm = 256; p->bn = 96; }
+    else { p->cfg = 2; p->bm = 128; p->bn = 128; }
+    p->mtiles = (p->M + p->bm - 1) / p->bm;
+    p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+    const long tiles = (long)p->mtiles * p->ntiles * p->par;
+    int sk = 1;
+    if (tiles < 256) {
+        sk = (int)((512 + tiles - 1) / tiles);
+        const int max_sk = p->kt_total / 4 > 0 ? p->kt_total / 4 : 1;
+        if (sk > max_sk) sk = max_sk;
+        if (sk > 64) sk = 64;
+        if (sk < 1) sk = 1;
+    }
+    p->splitk = sk;
+    return 0;
+}
+
+template <int KIND>
+static void launch_kind(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
+    const dim3 grid(pl.mtiles, pl.ntiles, pl.splitk * pl.par);
+    if (pl.cfg == 0) hipLaunchKernelGGL((conv_mfma_kernel<KIND, 4, 1, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
+    else if (pl.cfg == 1) hipLaunchKernelGGL((conv_mfma_kernel<KIND, 4, 1, 2, 3>), grid, dim3(CTHREADS), 0, st, P);
+    else hipLaunchKernelGGL((conv_mfma_kernel<KIND, 2, 2, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
+}
+
+static int check_desc(const rnr_conv_desc* d, const char* who) {
+    RNR_REQUIRE(d, "%s: null descriptor", who);
+    RNR_REQUIRE(d->kind >= 0 && d->kind <= 2, "%s: unknown kind %d", who, d->kind);
+    RNR_REQUIRE(d->c_in0 > 0 && d->c_in0_pad >= d->c_in0 && d->c_in0_pad % BK == 0,
+                "%s: c_in0 %d / pad %d (pad must be a multiple of %d)", who, d->c_in0, d->c_in0_pad, BK);
+    RNR_REQUIRE(d->c_in1 >= 0 && d->c_in1_pad >= d->c_in1 && d->c_in1_pad % BK == 0,
+                "%s: c_in1 %d / pad %d", who, d->c_in1, d->c_in1_pad);
+    RNR_REQUIRE(d->c_out > 0 && d->c_out_pad >= d->c_out && d->c_out_pad % BK == 0,
+                "%s: c_out %d / pad %d", who, d->c_out, d->c_out_pad);
+    return 0;
+}
+
+}  // namespace rnr
+
+using namespace rnr;
+
+extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
+    if (!d) return 0;
+    const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : (d->kind == RNR_CONV4x4S2_REFLECT ? 16 : 16);
+    return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)d->c_out_pad;
+}
+
+extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream) {
+    if (int e = check_desc(d, "rnr_pack_conv_weight")) return e;
+    RNR_REQUIRE(weight && packed, "rnr_pack_conv_weight: null pointer argument");
+    const long total = (long)rnr_packed_weight_floats(d);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       *d, weight, packed, total);
+    return check_launch("pack_weight_kernel");
+}
+
+extern "C" size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
+    if (!d || num_views <= 0) return 0;
+    ConvPlan pl;
+    make_plan(d, num_views, in_h, in_w, &pl);
+    if (pl.splitk <= 1) return 256;
+    return (size_t)pl.splitk * num_views * pl.OH * pl.OW * d->c_out_pad * sizeof(float) + 256;
+}
+
+extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                          const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
+                          int in_w, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d, "rnr_conv2d")) return e;
+    RNR_REQUIRE(src0 && src0->data && weight_packed && out_raw, "rnr_conv2d: null pointer argument");
+    RNR_REQUIRE(src0->channels == d->c_in0_pad, "rnr_conv2d: src0 has %d channels, descriptor says %d",
+                src0->channels, d->c_in0_pad);
+    RNR_REQUIRE(d->c_in1_pad == 0 || (src1 && src1->data && src1->channels == d->c_in1_pad),
+                "rnr_conv2d: second source missing or channel mismatch");
+    RNR_REQUIRE(num_views > 0 && in_h >= 2 && in_w >= 2, "rnr_conv2d: bad sizes N=%d H=%d W=%d", num_views, in_h, in_w);
+    RNR_REQUIRE(d->kind != RNR_CONV4x4S2_REFLECT || (in_h % 2 == 0 && in_w % 2 == 0),
+                "rnr_conv2d: stride-2 conv needs even input size");
+    hipStream_t st = as_stream(stream);
+    ConvPlan pl;
+    make_plan(d, num_views, in_h, in_w, &pl);
+    ConvParams P = {};
+    P.src_data[0] = src0->data; P.src_scale[0] = src0->scale; P.src_shift[0] = src0->shift;
+    P.src_c[0] = src0->channels; P.src_act[0] = src0->act;
+    if (d->c_in1_pad) {
+        P.src_data[1] = src1->data; P.src_scale[1] = src1->scale; P.src_shift[1] = src1->shift;
+        P.src_c[1] = src1->channels; P.src_act[1] = src1->act;
+    }
+    P.weight = weight_packed; P.stats = stats;
+    P.N = num_views; P.H = in_h; P.W = in_w; P.Ho = pl.Ho; P.Wo = pl.Wo; P.OH = pl.OH; P.OW = pl.OW; P.M = pl.M;
+    P.c_out = d->c_out; P.c_out_pad = d->c_out_pad;
+    P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
+    P.splitk = pl.splitk;
+    const size_t out_floats = (size_t)num_views * pl.OH * pl.OW * d->c_out_pad;
+    if (stats) RNR_HIP(hipMemsetAsync(stats, 0, (size_t)num_views * d->c_out_pad * 2 * sizeof(double), st));
+    if (pl.splitk > 1) {
+        RNR_REQUIRE(workspace && workspace_bytes >= (size_t)pl.splitk * out_floats * sizeof(float),
+                    "rnr_conv2d: workspace too small (%zu < %zu)", workspace_bytes,
+                    (size_t)pl.splitk * out_floats * sizeof(float));
+        P.out = reinterpret_cast<float*>(workspace);
+        P.slab_stride = (long)out_floats;
+    } else {
+        P.out = out_raw;
+        P.slab_stride = 0;
+    }
+    if (d->kind == RNR_CONV3x3_REFLECT) launch_kind<0>(pl, P, st);
+    else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_kind<1>(pl, P, st);
+    else launch_kind<2>(pl, P, st);
+    if (int e = check_launch("conv_mfma_kernel")) return e;
+    if (pl.splitk > 1) {
+        const long rows = (long)num_views * pl.OH * pl.OW;
+        const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((d->c_out_pad + 63) / 64));
+        hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, reinterpret_cast<const float*>(workspace),
+                           (long)out_floats, pl.splitk, out_raw, stats, rows, pl.OH * pl.OW, d->c_out, d->c_out_pad);
+        if (int e = check_launch("splitk_reduce_kernel")) return e;
+    }
+    return 0;
+}
+
+extern "C" int rnr_bn_finalize(const double* stats, const float* gamma, const float* beta, float* scale,
+                               float* shift, int num_views, int channels, int c_pad, double count, float eps,
+                               void* stream) {
+    RNR_REQUIRE(stats && gamma && beta && scale && shift, "rnr_bn_finalize: null pointer argument");
+    RNR_REQUIRE(num_views > 0 && channels > 0 && c_pad >= channels && count > 0, "rnr_bn_finalize: bad sizes");
+    const int total = num_views * c_pad;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), stats, gamma,
+                       beta, scale, shift, num_views, channels, c_pad, count, eps);
+    return check_launch("bn_finalize_kernel");
+}

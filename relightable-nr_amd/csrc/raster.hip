@@ -1,0 +1,529 @@
+// Tiled, order-preserving z-resolve rasterizer for gfx950 + fused G-buffer attribute interpolation.
+//
+// Replaces (does not translate) the reference's brute-force forward kernels
+//   forward_face_index_map_cuda_kernel_1/2  rasterize_cuda_kernel.cu:24-169   (O(pixels x faces))
+//   forward_texture_sampling_cuda_kernel    rasterize_cuda_kernel.cu:171-242
+// and, in the fused entry point, the torch glue of network.Rasterizer.forward (network.py:156-214).
+//
+// Design:
+//   1. face_setup_kernel, one lane per (view, face): back-face predicate, the 3x3 barycentric inverse
+//      (same IEEE binary32 operation sequence as the reference, this file is built with
+//      -ffp-contract=off), and a conservative pixel bounding box.  Faces whose box cannot be trusted
+//      (degenerate / sliver / non-finite) are flagged and decided by the exact tile test below.
+//   2. raster_tile_kernel, one 256-thread workgroup per 16x16-pixel tile: the workgroup scans the face
+//      boxes in ascending face order (8 B per face, coalesced), keeps the faces that can possibly pass
+//      the reference's inside test somewhere in the tile (exact, rounding-monotone tile test), compacts
+//      them IN ORDER into an LDS queue with wave ballots, and every lane (= pixel) then evaluates the
+//      reference's per-candidate arithmetic on LDS-broadcast face records.  Ascending order + strict `<`
+//      gives the reference's winner (first face with the smallest zp), so face_index_map, weight_map and
+//      depth_map are bit-identical to the reference evaluated without FMA contraction.
+//   3. epilogue: either the extension's maps (drop-in mode) or the perspective-corrected attribute
+//      interpolation of network.py:176-214 written once, already vertically flipped.
+#include "rnr_internal.h"
+
+namespace rnr {
+
+constexpr int TILE = 16;
+constexpr int RTHREADS = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_CHUNK = RTHREADS * SCAN_ITEMS;
+constexpr int QCAP = 2048;
+constexpr int STAGE_FLOATS = 24;
+
+struct __attribute__((aligned(8))) FaceBox {
+    short xlo, xhi, ylo, yhi;  // inclusive pixel-index bounds, rows in the kernel's native (unflipped) order
+};
+// xlo == BOX_EXACT : bounding box not trustworthy, the exact tile test decides
+// xlo >  xhi       : never a candidate (back face, or entirely off-screen)
+constexpr short BOX_EXACT = -2;
+
+__device__ __forceinline__ bool backface(const float* f) {
+    // rasterize_cuda_kernel.cu:40 / :111
+    return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
+}
+
+__device__ __forceinline__ float pix_center(int i, int is) {
+    // rasterize_cuda_kernel.cu:93-94: (2*i + 1 - is) / is  (exact small integer, one correctly rounded divide)
+    return (float)(2 * i + 1 - is) / (float)is;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. per-face setup
+// ------------------------------------------------------------------------------------------------
+template <bool GATHER>
+__global__ void __launch_bounds__(256)
+face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ v_uvz,
+                  const int32_t* __restrict__ fidx, float* __restrict__ faces_out,
+                  float* __restrict__ faces_inv, FaceBox* __restrict__ boxes, int batch, int nf, int nv,
+                  int is) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * nf) return;
+    float f[9];
+    if (GATHER) {  // vertices_to_faces.py:4-25 fused in
+        const int bn = (int)(i / nf), fn = (int)(i % nf);
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            const int vi = fidx[3 * fn + v];
+            const float* p = v_uvz + ((long)bn * nv + vi) * 3;
+            f[3 * v + 0] = p[0];
+            f[3 * v + 1] = p[1];
+            f[3 * v + 2] = p[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) faces_out[i * 9 + k] = f[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = faces_in[i * 9 + k];
+    }
+    FaceBox box;
+    if (backface(f)) {  // reference returns before writing: caller's zero fill stays (rasterize.py:163)
+        box.xlo = 1; box.xhi = 0; box.ylo = 1; box.yhi = 0;
+        boxes[i] = box;
+        if (GATHER) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = 0.0f;
+        }
+        return;
+    }
+    // ---- barycentric inverse, rasterize_cuda_kernel.cu:44-66 (operation order preserved) ----
+    const float s = (float)is;
+    float px[3], py[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        px[v] = 0.5f * (f[3 * v + 0] * s + s - 1.0f);
+        py[v] = 0.5f * (f[3 * v + 1] * s + s - 1.0f);
+    }
+    float m[9];
+    m[0] = py[1] - py[2]; m[1] = px[2] - px[1]; m[2] = px[1] * py[2] - px[2] * py[1];
+    m[3] = py[2] - py[0]; m[4] = px[0] - px[2]; m[5] = px[2] * py[0] - px[0] * py[2];
+    m[6] = py[0] - py[1]; m[7] = px[1] - px[0]; m[8] = px[0] * py[1] - px[1] * py[0];
+    const float den = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = m[k] / den;
+
+    // ---- conservative pixel bounding box (double; DESIGN.md §Rasterizer gives the bound) ----
+    const double x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+    const double minx = fmin(x0, fmin(x1, x2)), maxx = fmax(x0, fmax(x1, x2));
+    const double miny = fmin(y0, fmin(y1, y2)), maxy = fmax(y0, fmax(y1, y2));
+    const double maxabs = fmax(fmax(fabs(minx), fabs(maxx)), fmax(fabs(miny), fabs(maxy)));
+    const double ax = x1 - x0, ay = y1 - y0, bx = x2 - x0, by = y2 - y0, cx = x2 - x1, cy = y2 - y1;
+    const double area2 = fabs(ax * by - bx * ay);
+    const double l2 = fmax(ax * ax + ay * ay, fmax(bx * bx + by * by, cx * cx + cy * cy));
+    const double sin_min = area2 / l2;                         // <= sin(smallest interior angle)
+    const double u = 5.9604644775390625e-08;                   // 2^-24
+    const double pad_ndc = 4.0 * (32.0 * u * (1.0 + maxabs) / sin_min);
+    const double pad_px = pad_ndc * is * 0.5 + 1.0;
+    const bool finite = isfinite(maxabs);
+    if (!finite || !(sin_min > 0.0) || !(pad_px <= 16.0)) {
+        box.xlo = BOX_EXACT; box.xhi = (short)(is - 1); box.ylo = 0; box.yhi = (short)(is - 1);
+    } else {
+        double lx = floor(((minx - pad_ndc) * is + is - 1) * 0.5) - 1.0;
+        double hx = ceil(((maxx + pad_ndc) * is + is - 1) * 0.5) + 1.0;
+        double ly = floor(((miny - pad_ndc) * is + is - 1) * 0.5) - 1.0;
+        double hy = ceil(((maxy + pad_ndc) * is + is - 1) * 0.5) + 1.0;
+        lx = fmax(lx, 0.0); ly = fmax(ly, 0.0);
+        hx = fmin(hx, (double)(is - 1)); hy = fmin(hy, (double)(is - 1));
+        if (lx > hx || ly > hy) {
+            box.xlo = 1; box.xhi = 0; box.ylo = 1; box.yhi = 0;
+        } else {
+            box.xlo = (short)lx; box.xhi = (short)hx; box.ylo = (short)ly; box.yhi = (short)hy;
+        }
+    }
+    boxes[i] = box;
+}
+
+// Exact conservative tile test.  The reference rejects pixel p for edge a->b iff
+//     fl(fl(yp - ya) * fl(xb - xa)) < fl(fl(xp - xa) * fl(yb - ya))          (rasterize_cuda_kernel.cu:115-117)
+// Rounding is monotone, so over a tile the left product lies between its values at the tile's first/last
+// row and the right product between its values at the first/last column.  If all four corner comparisons
+// say "reject", every pixel of the tile rejects.  Any NaN makes a comparison false => tile kept.
+__device__ __forceinline__ bool edge_rejects_tile(float xa, float ya, float xb, float yb, float xlo,
+                                                  float xhi, float ylo, float yhi) {
+    const float dx = xb - xa, dy = yb - ya;
+    const float p0 = (ylo - ya) * dx, p1 = (yhi - ya) * dx;
+    const float q0 = (xlo - xa) * dy, q1 = (xhi - xa) * dy;
+    return (p0 < q0) && (p0 < q1) && (p1 < q0) && (p1 < q1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. tile kernel
+// ------------------------------------------------------------------------------------------------
+struct RasterParams {
+    const float* faces;      // [B,nf,9]
+    const float* faces_inv;  // [B,nf,9]
+    const FaceBox* boxes;    // [B,nf]
+    int nf, is;
+    float near_, far_;
+    int flip;                // 1: write row (is-1-yi)
+    // drop-in outputs (MODE 0)
+    int32_t* face_index_map;
+    float* weight_map;
+    float* depth_map;
+    float* face_inv_map;     // may be NULL
+    // fused outputs (MODE 1)
+    rnr_mesh mesh;
+    rnr_gbuffer gb;
+    const float* pose;       // [B,4,4] or NULL
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(RTHREADS)
+raster_tile_kernel(const RasterParams P) {
+    __shared__ int s_queue[QCAP];
+    __shared__ __attribute__((aligned(16))) float s_stage[RTHREADS * STAGE_FLOATS];
+    __shared__ int s_cnt[SCAN_ITEMS][RTHREADS / 64];
+
+    const int is = P.is, nf = P.nf;
+    const int tiles_x = (is + TILE - 1) / TILE;
+    const int tile = blockIdx.x;
+    const int bn = blockIdx.y;
+    const int tx0 = (tile % tiles_x) * TILE, ty0 = (tile / tiles_x) * TILE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int xi = tx0 + (tid & (TILE - 1)), yi = ty0 + (tid >> 4);
+    const bool in_img = (xi < is) && (yi < is);
+    const int tx1 = min(tx0 + TILE - 1, is - 1), ty1 = min(ty0 + TILE - 1, is - 1);
+    const float xp = pix_center(xi, is), yp = pix_center(yi, is);
+    const float fxi = (float)xi, fyi = (float)yi;
+    const float t_xlo = pix_center(tx0, is), t_xhi = pix_center(tx1, is);
+    const float t_ylo = pix_center(ty0, is), t_yhi = pix_center(ty1, is);
+
+    const float* faces = P.faces + (size_t)bn * nf * 9;
+    const float* faces_inv = P.faces_inv + (size_t)bn * nf * 9;
+    const FaceBox* boxes = P.boxes + (size_t)bn * nf;
+
+    float best_z = P.far_;
+    int best = -1;
+    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+    int qn = 0;
+
+    auto process_queue = [&]() {
+        for (int s0 = 0; s0 < qn; s0 += RTHREADS) {
+            const int n = min(RTHREADS, qn - s0);
+            if (tid < n) {
+                const int fn = s_queue[s0 + tid];
+                const float* f = faces + (size_t)fn * 9;
+                const float* fi = faces_inv + (size_t)fn * 9;
+                float4* dst = reinterpret_cast<float4*>(s_stage + tid * STAGE_FLOATS);
+                const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6],
+                            y2 = f[7], z2 = f[8];
+                dst[0] = make_float4(x0, y0, x1, y1);
+                dst[1] = make_float4(x2, y2, x1 - x0, y1 - y0);
+                dst[2] = make_float4(x2 - x1, y2 - y1, x0 - x2, y0 - y2);
+                dst[3] = make_float4(fi[0], fi[1], fi[2], fi[3]);
+                dst[4] = make_float4(fi[4], fi[5], fi[6], fi[7]);
+                dst[5] = make_float4(fi[8], z0, z1, z2);
+                // slot 5.x..: fi8, z0, z1, z2 ; the face index itself is re-read from s_queue
+            }
+            __syncthreads();
+            if (in_img) {
+                for (int c = 0; c < n; c++) {
+                    const float4* rec = reinterpret_cast<const float4*>(s_stage + c * STAGE_FLOATS);
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    // inside test (rasterize_cuda_kernel.cu:115-118)
+                    if ((yp - r0.y) * r1.z < (xp - r0.x) * r1.w) continue;
+                    if ((yp - r0.w) * r2.x < (xp - r0.z) * r2.y) continue;
+                    if ((yp - r1.y) * r2.z < (xp - r1.x) * r2.w) continue;
+                    const float4 r3 = rec[3], r4 = rec[4], r5 = rec[5];
+                    // w = face_inv * (xi, yi, 1), clamp, renormalise (cu:121-134)
+                    float w0 = r3.x * fxi + r3.y * fyi + r3.z;
+                    float w1 = r3.w * fxi + r4.x * fyi + r4.y;
+                    float w2 = r4.z * fxi + r4.w * fyi + r5.x;
+                    w0 = fminf(fmaxf(w0, 0.0f), 1.0f);
+                    w1 = fminf(fmaxf(w1, 0.0f), 1.0f);
+                    w2 = fminf(fmaxf(w2, 0.0f), 1.0f);
+                    float wsum = 0.0f;
+                    wsum += w0; wsum += w1; wsum += w2;
+                    w0 /= wsum; w1 /= wsum; w2 /= wsum;
+                    const float zp = 1.0f / (w0 / r5.y + w1 / r5.z + w2 / r5.w);   // cu:136
+                    if (zp <= P.near_ || P.far_ <= zp) continue;                    // cu:137-139
+                    if (zp < best_z) {                                              // cu:142
+                        best_z = zp;
+                        best = s_queue[s0 + c];
+                        bw0 = w0; bw1 = w1; bw2 = w2;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        qn = 0;
+    };
+
+    for (int base = 0; base < nf; base += SCAN_CHUNK) {
+        bool keep[SCAN_ITEMS];
+        int pre[SCAN_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const int fn = base + j * RTHREADS + tid;
+            bool k = false;
+            if (fn < nf) {
+                const FaceBox b = boxes[fn];
+                const bool exact_only = (b.xlo == BOX_EXACT);
+                if (exact_only || (b.xlo <= tx1 && b.xhi >= tx0 && b.ylo <= ty1 && b.yhi >= ty0)) {
+                    const float* f = faces + (size_t)fn * 9;
+                    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+                    k = !(edge_rejects_tile(x0, y0, x1, y1, t_xlo, t_xhi, t_ylo, t_yhi) ||
+                          edge_rejects_tile(x1, y1, x2, y2, t_xlo, t_xhi, t_ylo, t_yhi) ||
+                          edge_rejects_tile(x2, y2, x0, y0, t_xlo, t_xhi, t_ylo, t_yhi));
+                }
+            }
+            keep[j] = k;
+            const unsigned long long bal = __ballot(k);
+            pre[j] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[j][wave] = __popcll(bal);
+        }
+        __syncthreads();
+        int run = qn;
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+#pragma unroll
+            for (int w = 0; w < RTHREADS / 64; w++) {
+                const int c = s_cnt[j][w];
+                if (w == wave && keep[j]) s_queue[run + pre[j]] = base + j * RTHREADS + tid;
+                run += c;
+            }
+        }
+        qn = run;
+        __syncthreads();
+        if (qn > QCAP - SCAN_CHUNK) process_queue();
+    }
+    if (qn > 0) process_queue();
+
+    if (!in_img) return;
+    const int yo = P.flip ? (is - 1 - yi) : yi;
+    const size_t pix = ((size_t)bn * is + yo) * is + xi;
+
+    if (MODE == 0) {
+        if (best >= 0) {  // uncovered pixels keep the caller's pre-fill (cu:156-168)
+            P.depth_map[pix] = best_z;
+            P.face_index_map[pix] = best;
+            P.weight_map[3 * pix + 0] = bw0;
+            P.weight_map[3 * pix + 1] = bw1;
+            P.weight_map[3 * pix + 2] = bw2;
+            if (P.face_inv_map) {
+                const float* fi = faces_inv + (size_t)best * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) P.face_inv_map[9 * pix + k] = fi[k];
+            }
+        }
+        return;
+    }
+
+    // ---- MODE 1: network.Rasterizer.forward attribute interpolation (network.py:176-214) ----
+    const rnr_gbuffer& G = P.gb;
+    const int fa = best >= 0 ? best : nf - 1;  // torch indexing wraps -1 to the last face (weights are 0 there)
+    const float* f = faces + (size_t)fa * 9;
+    const float depth = best_z;                 // far on background (rasterize.py:52)
+    const float wp0 = ((1.0f / f[2]) * bw0) * depth;
+    const float wp1 = ((1.0f / f[5]) * bw1) * depth;
+    const float wp2 = ((1.0f / f[8]) * bw2) * depth;
+    if (G.face_index_map) G.face_index_map[pix] = best;
+    if (G.alpha) G.alpha[pix] = best >= 0 ? 1.0f : 0.0f;
+    if (G.depth) G.depth[pix] = depth;
+    if (G.raw_weight_map) {
+        G.raw_weight_map[3 * pix + 0] = bw0; G.raw_weight_map[3 * pix + 1] = bw1; G.raw_weight_map[3 * pix + 2] = bw2;
+    }
+    if (G.weight_map) {
+        G.weight_map[3 * pix + 0] = wp0; G.weight_map[3 * pix + 1] = wp1; G.weight_map[3 * pix + 2] = wp2;
+    }
+    if (G.uv_map) {
+        const int32_t* ti = P.mesh.f_vt_idx + (size_t)fa * 3;
+        const float* a = P.mesh.vt + (size_t)ti[0] * 2;
+        const float* b = P.mesh.vt + (size_t)ti[1] * 2;
+        const float* c = P.mesh.vt + (size_t)ti[2] * 2;
+        float u = a[0] * wp0 + b[0] * wp1 + c[0] * wp2;
+        float v = a[1] * wp0 + b[1] * wp1 + c[1] * wp2;
+        u = u - floorf(u);
+        v = v - floorf(v);
+        G.uv_map[2 * pix + 0] = u;
+        G.uv_map[2 * pix + 1] = v;
+    }
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0};
+    if (P.pose) {
+        const float* ps = P.pose + (size_t)bn * 16;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            R[3 * r + 0] = ps[4 * r + 0]; R[3 * r + 1] = ps[4 * r + 1]; R[3 * r + 2] = ps[4 * r + 2];
+            T[r] = ps[4 * r + 3];
+        }
+    }
+    if (G.normal_map || G.normal_map_cam) {
+        const int32_t* ni = P.mesh.f_vn_idx + (size_t)fa * 3;
+        const float* a = P.mesh.vn + (size_t)ni[0] * 3;
+        const float* b = P.mesh.vn + (size_t)ni[1] * 3;
+        const float* c = P.mesh.vn + (size_t)ni[2] * 3;
+        float n0 = a[0] * wp0 + b[0] * wp1 + c[0] * wp2;
+        float n1 = a[1] * wp0 + b[1] * wp1 + c[1] * wp2;
+        float n2 = a[2] * wp0 + b[2] * wp1 + c[2] * wp2;
+        float inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-12f);  // F.normalize
+        n0 *= inv; n1 *= inv; n2 *= inv;
+        if (G.normal_map) {
+            G.normal_map[3 * pix + 0] = n0; G.normal_map[3 * pix + 1] = n1; G.normal_map[3 * pix + 2] = n2;
+        }
+        if (G.normal_map_cam) {
+            float c0 = R[0] * n0 + R[1] * n1 + R[2] * n2;
+            float c1 = R[3] * n0 + R[4] * n1 + R[5] * n2;
+            float c2 = R[6] * n0 + R[7] * n1 + R[8] * n2;
+            float ic = 1.0f / fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);
+            G.normal_map_cam[3 * pix + 0] = c0 * ic;
+            G.normal_map_cam[3 * pix + 1] = c1 * ic;
+            G.normal_map_cam[3 * pix + 2] = c2 * ic;
+        }
+    }
+    if (G.position_map || G.position_map_cam) {
+        const int32_t* vi = P.mesh.f_v_idx + (size_t)fa * 3;
+        const float* a = P.mesh.v + (size_t)vi[0] * 3;
+        const float* b = P.mesh.v + (size_t)vi[1] * 3;
+        const float* c = P.mesh.v + (size_t)vi[2] * 3;
+        const float p0 = a[0] * wp0 + b[0] * wp1 + c[0] * wp2;
+        const float p1 = a[1] * wp0 + b[1] * wp1 + c[1] * wp2;
+        const float p2 = a[2] * wp0 + b[2] * wp1 + c[2] * wp2;
+        if (G.position_map) {
+            G.position_map[3 * pix + 0] = p0; G.position_map[3 * pix + 1] = p1; G.position_map[3 * pix + 2] = p2;
+        }
+        if (G.position_map_cam) {
+            G.position_map_cam[3 * pix + 0] = R[0] * p0 + R[1] * p1 + R[2] * p2 + T[0];
+            G.position_map_cam[3 * pix + 1] = R[3] * p0 + R[4] * p1 + R[5] * p2 + T[1];
+            G.position_map_cam[3 * pix + 2] = R[6] * p0 + R[7] * p1 + R[8] * p2 + T[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-face texture cube sampling (API completeness; the hot path passes an all-zero texture)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+texture_sampling_kernel(const float* __restrict__ faces, const float* __restrict__ textures,
+                        const int32_t* __restrict__ face_index_map, const float* __restrict__ weight_map,
+                        const float* __restrict__ depth_map, float* __restrict__ rgb_map,
+                        int32_t* __restrict__ sampling_index_map, float* __restrict__ sampling_weight_map,
+                        long npix, int nf, int is, int ts, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const int fidx = face_index_map[i];
+    if (fidx < 0) return;
+    const int bn = (int)(i / ((long)is * is));
+    const float* f = faces + ((size_t)bn * nf + fidx) * 9;
+    const float* tex = textures + ((size_t)bn * nf + fidx) * ts * ts * ts * 3;
+    const float depth = depth_map[i];
+    float t[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {  // cu:208-213
+        float v = weight_map[3 * i + k] * (float)(ts - 1) * (depth / f[3 * k + 2]);
+        v = fmaxf(v, 0.0f);
+        v = fminf(v, (float)(ts - 1) - eps);
+        t[k] = v;
+    }
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {  // cu:217-236
+        float w = 1.0f;
+        int ti[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int b = (int)t[k];
+            const float frac = t[k] - (float)b;
+            if (((corner >> k) & 1) == 0) { w *= 1.0f - frac; ti[k] = b; }
+            else                          { w *= frac;        ti[k] = b + 1; }
+        }
+        const int isc = ti[0] * ts * ts + ti[1] * ts + ti[2];
+        acc0 += w * tex[isc * 3 + 0];
+        acc1 += w * tex[isc * 3 + 1];
+        acc2 += w * tex[isc * 3 + 2];
+        sampling_index_map[8 * i + corner] = isc;
+        sampling_weight_map[8 * i + corner] = w;
+    }
+    rgb_map[3 * i + 0] = acc0; rgb_map[3 * i + 1] = acc1; rgb_map[3 * i + 2] = acc2;
+}
+
+static size_t box_bytes(int batch, int nf) { return align_up((size_t)batch * nf * sizeof(FaceBox), 256); }
+static size_t face_bytes(int batch, int nf) { return align_up((size_t)batch * nf * 9 * sizeof(float), 256); }
+
+}  // namespace rnr
+
+using namespace rnr;
+
+extern "C" size_t rnr_raster_workspace_bytes(int batch_size, int num_faces) {
+    return box_bytes(batch_size, num_faces);
+}
+
+extern "C" int rnr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
+                                          float* depth_map, float* face_inv_map, float* faces_inv,
+                                          int batch_size, int num_faces, int image_size, float near_,
+                                          float far_, int return_rgb, int return_alpha, int return_depth,
+                                          void* workspace, void* stream) {
+    (void)return_rgb; (void)return_alpha;
+    RNR_REQUIRE(faces && face_index_map && weight_map && depth_map && faces_inv && workspace,
+                "rnr_forward_face_index_map: null pointer argument");
+    RNR_REQUIRE(batch_size > 0 && num_faces > 0 && image_size > 0 && image_size <= 16384,
+                "rnr_forward_face_index_map: bad sizes B=%d nf=%d is=%d", batch_size, num_faces, image_size);
+    RNR_REQUIRE(!return_depth || face_inv_map, "rnr_forward_face_index_map: return_depth needs face_inv_map");
+    hipStream_t st = as_stream(stream);
+    FaceBox* boxes = reinterpret_cast<FaceBox*>(workspace);
+    const long total = (long)batch_size * num_faces;
+    hipLaunchKernelGGL(face_setup_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces,
+                       nullptr, nullptr, nullptr, faces_inv, boxes, batch_size, num_faces, 0, image_size);
+    if (int e = check_launch("face_setup_kernel")) return e;
+    RasterParams P = {};
+    P.faces = faces; P.faces_inv = faces_inv; P.boxes = boxes; P.nf = num_faces; P.is = image_size;
+    P.near_ = near_; P.far_ = far_; P.flip = 0;
+    P.face_index_map = face_index_map; P.weight_map = weight_map; P.depth_map = depth_map;
+    P.face_inv_map = return_depth ? face_inv_map : nullptr;
+    const int tiles = (image_size + TILE - 1) / TILE;
+    hipLaunchKernelGGL(raster_tile_kernel<0>, dim3(tiles * tiles, batch_size), dim3(RTHREADS), 0, st, P);
+    return check_launch("raster_tile_kernel<0>");
+}
+
+extern "C" int rnr_forward_texture_sampling(const float* faces, const float* textures,
+                                            const int32_t* face_index_map, const float* weight_map,
+                                            const float* depth_map, float* rgb_map,
+                                            int32_t* sampling_index_map, float* sampling_weight_map,
+                                            int batch_size, int num_faces, int image_size, int texture_size,
+                                            float eps, void* stream) {
+    RNR_REQUIRE(faces && textures && face_index_map && weight_map && depth_map && rgb_map &&
+                    sampling_index_map && sampling_weight_map,
+                "rnr_forward_texture_sampling: null pointer argument");
+    RNR_REQUIRE(batch_size > 0 && num_faces > 0 && image_size > 0 && texture_size > 1,
+                "rnr_forward_texture_sampling: bad sizes");
+    const long npix = (long)batch_size * image_size * image_size;
+    hipLaunchKernelGGL(texture_sampling_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), faces, textures, face_index_map, weight_map, depth_map, rgb_map,
+                       sampling_index_map, sampling_weight_map, npix, num_faces, image_size, texture_size, eps);
+    return check_launch("texture_sampling_kernel");
+}
+
+extern "C" size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces) {
+    return box_bytes(num_views, num_faces) + 2 * face_bytes(num_views, num_faces);
+}
+
+extern "C" int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, const float* pose,
+                                     int num_views, int image_size, float near_, float far_,
+                                     const rnr_gbuffer* out, void* workspace, void* stream) {
+    RNR_REQUIRE(mesh && v_uvz && out && workspace, "rnr_rasterize_gbuffer: null pointer argument");
+    RNR_REQUIRE(mesh->v && mesh->f_v_idx && mesh->num_faces > 0 && mesh->num_vertices > 0,
+                "rnr_rasterize_gbuffer: incomplete mesh");
+    RNR_REQUIRE(!(out->uv_map) || (mesh->vt && mesh->f_vt_idx), "rnr_rasterize_gbuffer: uv_map needs vt");
+    RNR_REQUIRE(!(out->normal_map || out->normal_map_cam) || (mesh->vn && mesh->f_vn_idx),
+                "rnr_rasterize_gbuffer: normal maps need vn");
+    RNR_REQUIRE(!(out->normal_map_cam || out->position_map_cam) || pose,
+                "rnr_rasterize_gbuffer: camera-space maps need pose");
+    RNR_REQUIRE(num_views > 0 && image_size > 0 && image_size <= 16384, "rnr_rasterize_gbuffer: bad sizes");
+    hipStream_t st = as_stream(stream);
+    const int nf = mesh->num_faces;
+    char* ws = reinterpret_cast<char*>(workspace);
+    FaceBox* boxes = reinterpret_cast<FaceBox*>(ws);
+    float* faces = reinterpret_cast<float*>(ws + box_bytes(num_views, nf));
+    float* faces_inv = reinterpret_cast<float*>(ws + box_bytes(num_views, nf) + face_bytes(num_views, nf));
+    const long total = (long)num_views * nf;
+    hipLaunchKernelGGL(face_setup_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nullptr,
+                       v_uvz, mesh->f_v_idx, faces, faces_inv, boxes, num_views, nf, mesh->num_vertices,
+                       image_size);
+    if (int e = check_launch("face_setup_kernel<gather>")) return e;
+    RasterParams P = {};
+    P.faces = faces; P.faces_inv = faces_inv; P.boxes = boxes; P.nf = nf; P.is = image_size;
+    P.near_ = near_; P.far_ = far_; P.flip = 1;
+    P.mesh = *mesh; P.gb = *out; P.pose = pose;
+    const int tiles = (image_size + TILE - 1) / TILE;
+    hipLaunchKernelGGL(raster_tile_kernel<1>, dim3(tiles * tiles, num_views), dim3(RTHREADS), 0, st, P);
+    return check_launch("raster_tile_kernel<1>");
+}

@@ -1,0 +1,650 @@
+// Shading-side kernels of the hot path (everything between the rasterizer and the U-Net, and after it).
+//
+//   project_vertices_kernel   nr.projection                      projection.py:6-53
+//   face_tangents_kernel      per-face tangent of get_TBN_map    render.py:135-150
+//   shade_inputs_kernel       TBN + view dir + SH(lmax 2) + 4-level neural texture + 26 rays + channel
+//                             assembly -> channel-last network input, written once, coalesced
+//                             (render.py:152-166, camera.py:5-45, test_rnr.py:303-356, network.py:67-91,
+//                              network.py:445-472, misc.py:5-42, sph_harm.py:41-71)
+//   ray_render_kernel         out-layer bias + tanh + RayRenderer (network.py:253, 481-527; test_rnr.py:357-359)
+//   sh_basis / sh_reconstruct / sh_fit / interpolate_bilinear / layout helpers
+//
+// Built with -ffp-contract=off: the integer tap indices of the bilinear sampler (misc.py:16-25) must be the
+// bits the reference's float32 expressions produce (u*(S-1), (S-1) - v*(S-1), floor), so no FMA contraction.
+#include "rnr_internal.h"
+
+namespace rnr {
+
+#define RNR_PI_F 3.14159265358979323846f
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// torch.nn.functional.normalize: x / max(||x||_2, 1e-12)
+__device__ __forceinline__ float3 normalize3(float3 a) {
+    const float n = fmaxf(sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), 1e-12f);
+    return f3(a.x / n, a.y / n, a.z / n);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+project_vertices_kernel(const float* __restrict__ vertices, const float* __restrict__ K,
+                        const float* __restrict__ R, const float* __restrict__ t,
+                        const float* __restrict__ dist, const float* __restrict__ offset,
+                        const float* __restrict__ scale, float* __restrict__ out, int nviews, int nv,
+                        float orig_size, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)nviews * nv) return;
+    const int n = (int)(i / nv), vi = (int)(i % nv);
+    const float* p = vertices + (size_t)vi * 3;
+    const float* Rn = R + n * 9;
+    const float* Kn = K + n * 9;
+    const float vx = p[0], vy = p[1], vz = p[2];
+    // vertices . R^T + t   (projection.py:22)
+    const float x = vx * Rn[0] + vy * Rn[1] + vz * Rn[2] + t[n * 3 + 0];
+    const float y = vx * Rn[3] + vy * Rn[4] + vz * Rn[5] + t[n * 3 + 1];
+    const float z = vx * Rn[6] + vy * Rn[7] + vz * Rn[8] + t[n * 3 + 2];
+    const float xn = x / (z + eps), yn = y / (z + eps);
+    float k1 = 0.f, k2 = 0.f, p1 = 0.f, p2 = 0.f, k3 = 0.f;
+    if (dist) { k1 = dist[n * 5 + 0]; k2 = dist[n * 5 + 1]; p1 = dist[n * 5 + 2]; p2 = dist[n * 5 + 3]; k3 = dist[n * 5 + 4]; }
+    const float r = sqrtf(xn * xn + yn * yn);
+    const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
+    const float radial = 1.0f + k1 * r2 + k2 * r4 + k3 * r6;
+    const float xd = xn * radial + 2.0f * p1 * xn * yn + p2 * (r2 + 2.0f * xn * xn);
+    const float yd = yn * radial + p1 * (r2 + 2.0f * yn * yn) + 2.0f * p2 * xn * yn;
+    float u = xd * Kn[0] + yd * Kn[1] + Kn[2];
+    float v = xd * Kn[3] + yd * Kn[4] + Kn[5];
+    if (offset && scale) {  // projection.py:42-46 (note the swapped component order)
+        u = (u + offset[n * 2 + 1]) * scale[n * 2 + 1];
+        v = (v + offset[n * 2 + 0]) * scale[n * 2 + 0];
+    }
+    v = orig_size - v;
+    u = 2.0f * (u - orig_size / 2.0f) / orig_size;
+    v = 2.0f * (v - orig_size / 2.0f) / orig_size;
+    out[i * 3 + 0] = u;
+    out[i * 3 + 1] = v;
+    out[i * 3 + 2] = z;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+face_tangents_kernel(rnr_mesh mesh, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mesh.num_faces) return;
+    const int32_t* vi = mesh.f_v_idx + (size_t)i * 3;
+    const int32_t* ti = mesh.f_vt_idx + (size_t)i * 3;
+    const float* a = mesh.v + (size_t)vi[0] * 3;
+    const float* b = mesh.v + (size_t)vi[1] * 3;
+    const float* c = mesh.v + (size_t)vi[2] * 3;
+    const float* ta = mesh.vt + (size_t)ti[0] * 2;
+    const float* tb = mesh.vt + (size_t)ti[1] * 2;
+    const float* tc = mesh.vt + (size_t)ti[2] * 2;
+    const float3 e1 = f3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
+    const float3 e2 = f3(c[0] - a[0], c[1] - a[1], c[2] - a[2]);
+    const float d1x = tb[0] - ta[0], d1y = tb[1] - ta[1];
+    const float d2x = tc[0] - ta[0], d2y = tc[1] - ta[1];
+    const float f = 1.0f / fmaxf(d1x * d2y - d2x * d1y, 1e-8f);   // clamp(min=1e-8), render.py:143
+    const float3 tn = normalize3(f3(f * (d2y * e1.x - d1y * e2.x), f * (d2y * e1.y - d1y * e2.y),
+                                    f * (d2y * e1.z - d1y * e2.z)));
+    out[i * 3 + 0] = tn.x; out[i * 3 + 1] = tn.y; out[i * 3 + 2] = tn.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear taps of misc.interpolate_bilinear (misc.py:14-40)
+struct Taps {
+    int x0, y0, x1, y1;
+    float w00, w10, w01, w11;
+};
+__device__ __forceinline__ Taps bilinear_taps(float x, float y, int W, int H) {
+    Taps t;
+    const float valid = (x >= 0.0f && x <= (float)(W - 1) && y >= 0.0f && y <= (float)(H - 1)) ? 1.0f : 0.0f;
+    // floor -> int64 in the reference; clamp in float first so NaN / huge coordinates stay defined
+    const float fx = floorf(x), fy = floorf(y);
+    int x0 = (int)fminf(fmaxf(fx, -2.0f), (float)W + 1.0f);
+    int y0 = (int)fminf(fmaxf(fy, -2.0f), (float)H + 1.0f);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+    y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+    t.x0 = x0; t.y0 = y0; t.x1 = x1; t.y1 = y1;
+    const float x0w = (float)(x0 - (x0 == x1 ? 1 : 0)), y0w = (float)(y0 - (y0 == y1 ? 1 : 0));
+    const float x1f = (float)x1, y1f = (float)y1;
+    t.w00 = (x1f - x) * (y1f - y) * valid;
+    t.w10 = (x1f - x) * (y - y0w) * valid;
+    t.w01 = (x - x0w) * (y1f - y) * valid;
+    t.w11 = (x - x0w) * (y - y0w) * valid;
+    return t;
+}
+
+constexpr int SH_PIX = 64;        // pixels per workgroup
+constexpr int SH_THREADS = 256;
+constexpr int MAX_LEVELS = 8;
+constexpr int MAX_RAYS = 32;
+
+struct ShadeParams {
+    const int32_t* face_index_map;
+    const float* alpha;
+    const float* uv_map;
+    const float* normal_map;
+    const float* tangents;
+    int num_faces;
+    const float* proj_inv;
+    const float* R_inv;
+    const float* tex[MAX_LEVELS];
+    int tex_size[MAX_LEVELS];
+    int num_levels, C, sh_start;
+    float piv_spec[MAX_RAYS * 3];   // [r][xyz]
+    float piv_diff[MAX_RAYS * 3];
+    int n_spec, n_diff;
+    float* net_in;
+    int c_pad;
+    float* rays_uv;
+    float* neural_img;
+    float* sh_basis_map;
+    long npix;                      // N*H*W
+    int H, W;
+};
+
+// geometry record per pixel in LDS: T(3) B(3) N(3) vtan(3) uv(2) alpha(1) sh(9) = 24 floats
+constexpr int GEO = 24;
+
+__global__ void __launch_bounds__(SH_THREADS)
+shade_inputs_kernel(const ShadeParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                               // [SH_PIX][c_pad]
+    float* geo = smem + SH_PIX * P.c_pad;             // [SH_PIX][GEO]
+    const int tid = threadIdx.x;
+    const long pix0 = (long)blockIdx.x * SH_PIX;
+    const int cp = P.c_pad;
+    const int n_rays = P.n_spec + P.n_diff;
+    const int c_geo = 3 * n_rays;                     // first channel of normal
+
+    // zero the padding channels once
+    const int c_in = c_geo + 6 + P.C;
+    for (int i = tid; i < SH_PIX * (cp - c_in); i += SH_THREADS) {
+        const int p = i / (cp - c_in), c = c_in + i % (cp - c_in);
+        tile[p * cp + c] = 0.0f;
+    }
+
+    // ---- phase 0: one lane per pixel: TBN, view direction, SH basis ----
+    if (tid < SH_PIX) {
+        const long pix = pix0 + tid;
+        float* g = geo + tid * GEO;
+        if (pix < P.npix) {
+            const int hw = P.H * P.W;
+            const int n = (int)(pix / hw);
+            const int rem = (int)(pix % hw);
+            const int row = rem / P.W, col = rem % P.W;
+            int fi = P.face_index_map[pix];
+            if (fi < 0) fi += P.num_faces;            // torch negative index wrap (render.py:152)
+            const float a = P.alpha[pix];
+            const float3 tg = f3(P.tangents[fi * 3 + 0], P.tangents[fi * 3 + 1], P.tangents[fi * 3 + 2]);
+            const float3 nm_in = f3(P.normal_map[pix * 3 + 0], P.normal_map[pix * 3 + 1], P.normal_map[pix * 3 + 2]);
+            const float3 nm = normalize3(nm_in);                        // render.py:155
+            const float3 bt = normalize3(cross3(nm, tg));               // render.py:156-157
+            const float3 tt = normalize3(cross3(bt, nm));               // render.py:160-161
+            // view direction (camera.py:19-30)
+            const float* Pi = P.proj_inv + n * 9;
+            const float* Ri = P.R_inv + n * 9;
+            const float pu = (float)col + 0.5f, pv = (float)row + 0.5f;
+            float3 dc = f3(-(Pi[0] * pu + Pi[1] * pv + Pi[2]), -(Pi[3] * pu + Pi[4] * pv + Pi[5]),
+                           -(Pi[6] * pu + Pi[7] * pv + Pi[8]));
+            dc = normalize3(dc);
+            float3 vd = f3(Ri[0] * dc.x + Ri[1] * dc.y + Ri[2] * dc.z, Ri[3] * dc.x + Ri[4] * dc.y + Ri[5] * dc.z,
+                           Ri[6] * dc.x + Ri[7] * dc.y + Ri[8] * dc.z);
+            vd = normalize3(vd);
+            // tangent-space view direction = normalize(TBN^T v) (test_rnr.py:314-315)
+            const float3 vt = normalize3(f3(dot3(tt, vd), dot3(bt, vd), dot3(nm, vd)));
+            g[0] = tt.x; g[1] = tt.y; g[2] = tt.z;
+            g[3] = bt.x; g[4] = bt.y; g[5] = bt.z;
+            g[6] = nm.x; g[7] = nm.y; g[8] = nm.z;
+            g[9] = vt.x; g[10] = vt.y; g[11] = vt.z;
+            g[12] = P.uv_map[pix * 2 + 0]; g[13] = P.uv_map[pix * 2 + 1];
+            g[14] = a;
+            // real SH, lmax = 2, orthonormal, no Condon-Shortley phase, colatitude from +z
+            const float3 d = normalize3(vd);
+            float* sh = g + 15;
+            sh[0] = 0.28209479177387814f;
+            sh[1] = 0.4886025119029199f * d.y;
+            sh[2] = 0.4886025119029199f * d.z;
+            sh[3] = 0.4886025119029199f * d.x;
+            sh[4] = 1.0925484305920792f * d.x * d.y;
+            sh[5] = 1.0925484305920792f * d.y * d.z;
+            sh[6] = 0.31539156525252005f * (3.0f * d.z * d.z - 1.0f);
+            sh[7] = 1.0925484305920792f * d.x * d.z;
+            sh[8] = 0.5462742152960396f * (d.x * d.x - d.y * d.y);
+            if (P.sh_basis_map) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) P.sh_basis_map[pix * 9 + k] = sh[k];
+            }
+            float* tp = tile + tid * cp + c_geo;      // channels: normal (3), view_dir (3) (test_rnr.py:351-352)
+            tp[0] = nm_in.x; tp[1] = nm_in.y; tp[2] = nm_in.z;
+            tp[3] = vd.x; tp[4] = vd.y; tp[5] = vd.z;
+        } else {
+            for (int k = 0; k < GEO; k++) g[k] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: (pixel, ray) items: reflect / diffuse directions (network.py:455-465) ----
+    for (int i = tid; i < SH_PIX * n_rays; i += SH_THREADS) {
+        const int p = i % SH_PIX, r = i / SH_PIX;
+        const float* g = geo + p * GEO;
+        const float3 tt = f3(g[0], g[1], g[2]), bt = f3(g[3], g[4], g[5]), nm = f3(g[6], g[7], g[8]);
+        const float a = g[14];
+        float3 lt;   // direction in tangent space
+        if (r < P.n_spec) {
+            const float3 pv = f3(P.piv_spec[r * 3 + 0], P.piv_spec[r * 3 + 1], P.piv_spec[r * 3 + 2]);
+            const float3 v = f3(g[9], g[10], g[11]);
+            const float s = dot3(pv, v) * 2.0f;                         // camera.py:43
+            lt = normalize3(f3(s * pv.x - v.x, s * pv.y - v.y, s * pv.z - v.z));
+            lt = f3(lt.x * a, lt.y * a, lt.z * a);
+        } else {
+            const int rd = r - P.n_spec;
+            lt = f3(P.piv_diff[rd * 3 + 0], P.piv_diff[rd * 3 + 1], P.piv_diff[rd * 3 + 2]);
+        }
+        float3 d = f3(tt.x * lt.x + bt.x * lt.y + nm.x * lt.z, tt.y * lt.x + bt.y * lt.y + nm.y * lt.z,
+                      tt.z * lt.x + bt.z * lt.y + nm.z * lt.z);        // TBN . lt (columns T,B,N)
+        d = normalize3(d);
+        float* tp = tile + p * cp + 3 * r;                              // ray-major, xyz inner (test_rnr.py:350)
+        tp[0] = d.x; tp[1] = d.y; tp[2] = d.z;
+        if (P.rays_uv) {
+            const long pix = pix0 + p;
+            if (pix < P.npix) {                                         // render.py:96-102, network.py:469-470
+                float u = atan2f(d.z, d.x) * 0.5f / RNR_PI_F + 0.5f;
+                float v = acosf(d.y) * 1.0f / RNR_PI_F;
+                const float bg = (a == 0.0f) ? 1.0f : 0.0f;
+                u = u * a - bg;
+                v = v * a - bg;
+                P.rays_uv[(pix * 2 + 0) * n_rays + r] = u;
+                P.rays_uv[(pix * 2 + 1) * n_rays + r] = v;
+            }
+        }
+    }
+
+    // ---- phase 2: (pixel, channel-quad) items: sum over levels of bilinear fetches (network.py:71-85) ----
+    const int quads = P.C / 4;
+    for (int i = tid; i < SH_PIX * quads; i += SH_THREADS) {
+        const int q = i % quads, p = i / quads;
+        const float* g = geo + p * GEO;
+        const float u = g[12], v = g[13];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < P.num_levels; l++) {
+            const int s = P.tex_size[l];
+            const float sm1 = (float)(s - 1);
+            const float x = u * sm1;
+            const float y = sm1 - v * sm1;
+            const Taps t = bilinear_taps(x, y, s, s);
+            const float4* tex = reinterpret_cast<const float4*>(P.tex[l]);
+            const float4 i00 = tex[((size_t)t.y0 * s + t.x0) * quads + q];
+            const float4 i10 = tex[((size_t)t.y1 * s + t.x0) * quads + q];
+            const float4 i01 = tex[((size_t)t.y0 * s + t.x1) * quads + q];
+            const float4 i11 = tex[((size_t)t.y1 * s + t.x1) * quads + q];
+            float4 lv;   // I00*w00 + I10*w10 + I01*w01 + I11*w11 (misc.py:42)
+            lv.x = i00.x * t.w00 + i10.x * t.w10 + i01.x * t.w01 + i11.x * t.w11;
+            lv.y = i00.y * t.w00 + i10.y * t.w10 + i01.y * t.w01 + i11.y * t.w11;
+            lv.z = i00.z * t.w00 + i10.z * t.w10 + i01.z * t.w01 + i11.z * t.w11;
+            lv.w = i00.w * t.w00 + i10.w * t.w10 + i01.w * t.w01 + i11.w * t.w11;
+            if (l == 0) acc = lv;
+            else { acc.x += lv.x; acc.y += lv.y; acc.z += lv.z; acc.w += lv.w; }
+        }
+        if (P.sh_start >= 0) {  // output[:, s:s+9] *= sh_basis (network.py:88-89)
+            const float* sh = g + 15;
+            const int c0 = 4 * q - P.sh_start;
+            if (c0 + 0 >= 0 && c0 + 0 < 9) acc.x *= sh[c0 + 0];
+            if (c0 + 1 >= 0 && c0 + 1 < 9) acc.y *= sh[c0 + 1];
+            if (c0 + 2 >= 0 && c0 + 2 < 9) acc.z *= sh[c0 + 2];
+            if (c0 + 3 >= 0 && c0 + 3 < 9) acc.w *= sh[c0 + 3];
+        }
+        float* tp = tile + p * cp + c_geo + 6 + 4 * q;
+        tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w;
+    }
+    __syncthreads();
+
+    // ---- phase 3: one coalesced sweep of the tile to HBM ----
+    const long valid_pix = min((long)SH_PIX, P.npix - pix0);
+    const int n4 = (int)(valid_pix * cp / 4);
+    float4* dst = reinterpret_cast<float4*>(P.net_in + pix0 * cp);
+    const float4* src = reinterpret_cast<const float4*>(tile);
+    for (int i = tid; i < n4; i += SH_THREADS) dst[i] = src[i];
+    if (P.neural_img) {  // [N, C, H, W] copy for the API (TextureMapper.forward's return value)
+        const int hw = P.H * P.W;
+        for (int i = tid; i < (int)valid_pix * P.C; i += SH_THREADS) {
+            const int p = i % SH_PIX, c = i / SH_PIX;
+            if (p < valid_pix) {
+                const long pix = pix0 + p;
+                const long n = pix / hw, rem = pix % hw;
+                P.neural_img[(n * P.C + c) * hw + rem] = tile[p * cp + c_geo + 6 + c];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray renderer: 32 lanes per pixel (one ray each), 16-lane segmented shuffle reductions.
+// lane layout inside a 32-lane half: lanes 0..15 -> specular rays 0..15, lanes 16..31 -> diffuse rays 0..15
+// ------------------------------------------------------------------------------------------------
+struct RayParams {
+    const float* unet_raw; int c_out_pad;
+    const float* bias;
+    const float* net_in; int c_pad;
+    const float* alpha;
+    const float* lp; int lp_h, lp_w;
+    int n_spec, n_diff, alb_diff_ch, alb_spec_ch;
+    float* image;
+    long npix; int hw;
+};
+
+__device__ __forceinline__ float seg16_sum(float v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+ray_render_kernel(const RayParams P) {
+    const long gl = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pix = gl >> 5;
+    const int sub = (int)(gl & 31);
+    const bool is_diff = sub >= 16;
+    const int rr = sub & 15;
+    const bool live = (pix < P.npix) && (is_diff ? rr < P.n_diff : rr < P.n_spec);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (live) {
+        const int r = is_diff ? P.n_spec + rr : rr;
+        const float a = P.alpha[pix];
+        const float* d = P.net_in + pix * P.c_pad + 3 * r;
+        const float dx = d[0], dy = d[1], dz = d[2];
+        // rays_uv (render.py:96-102; network.py:469-470)
+        float u = atan2f(dz, dx) * 0.5f / RNR_PI_F + 0.5f;
+        float v = acosf(dy) * 1.0f / RNR_PI_F;
+        const float bg = (a == 0.0f) ? 1.0f : 0.0f;
+        u = u * a - bg;
+        v = v * a - bg;
+        // env-map taps (network.py:497; misc.py:5-42): clamp(max=) only, then the validity mask zeroes uv=-1
+        const float x = fminf(u * (float)P.lp_w, (float)(P.lp_w - 1));
+        const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
+        const Taps t = bilinear_taps(x, y, P.lp_w, P.lp_h);
+        const float* l00 = P.lp + ((size_t)t.y0 * P.lp_w + t.x0) * 3;
+        const float* l10 = P.lp + ((size_t)t.y1 * P.lp_w + t.x0) * 3;
+        const float* l01 = P.lp + ((size_t)t.y0 * P.lp_w + t.x1) * 3;
+        const float* l11 = P.lp + ((size_t)t.y1 * P.lp_w + t.x1) * 3;
+        const float* y_raw = P.unet_raw + pix * P.c_out_pad + 3 * r;
+        const float* b = P.bias + 3 * r;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float col = l00[c] * t.w00 + l10[c] * t.w10 + l01[c] * t.w01 + l11[c] * t.w11;
+            const float lt = (tanhf(y_raw[c] + b[c]) * 0.5f + 0.5f) * 2.0f;   // network.py:253; test_rnr.py:359
+            const float prod = lt * col;
+            if (c == 0) c0 = prod; else if (c == 1) c1 = prod; else c2 = prod;
+        }
+    }
+    c0 = seg16_sum(c0); c1 = seg16_sum(c1); c2 = seg16_sum(c2);
+    // lane 0 of each 16-lane segment holds its segment's sum; bring the diffuse sum to the pixel's first lane
+    const float d0 = __shfl_down(c0, 16, 64), d1 = __shfl_down(c1, 16, 64), d2 = __shfl_down(c2, 16, 64);
+    if (sub == 0 && pix < P.npix) {
+        const float* ni = P.net_in + pix * P.c_pad + 3 * (P.n_spec + P.n_diff) + 6;
+        const float inv_s = 1.0f / (float)P.n_spec;
+        const long n = pix / P.hw, rem = pix % P.hw;
+        float o[3] = {c0, c1, c2}, dd[3] = {d0, d1, d2};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float out = ni[P.alb_spec_ch + c] * (o[c] / (float)P.n_spec);
+            if (P.n_diff > 0) out = out + ni[P.alb_diff_ch + c] * (dd[c] / (float)P.n_diff);
+            P.image[(n * 3 + c) * P.hw + rem] = out;
+        }
+        (void)inv_s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// spherical harmonics, float64 internally like the reference's numpy/pyshtools path
+// ------------------------------------------------------------------------------------------------
+constexpr int SH_LMAX_MAX = 16;
+
+__global__ void __launch_bounds__(128)
+sh_basis_kernel(const float* __restrict__ dirs, float* __restrict__ out, int n, int lmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = dirs[i * 3 + 0], y = dirs[i * 3 + 1], z = dirs[i * 3 + 2];
+    // sph_harm.py:14-15, 54-57: azimuth = atan2(y,x); colatitude = pi/2 - atan2(z, sqrt(x^2+y^2))
+    const double rho = sqrt(x * x + y * y);
+    const double phi = atan2(y, x);
+    const double rr = sqrt(rho * rho + z * z);
+    const double ct = rr > 0.0 ? z / rr : 1.0, st = rr > 0.0 ? rho / rr : 0.0;
+    const int nb = (lmax + 1) * (lmax + 1);
+    float* o = out + (size_t)i * nb;
+    const double fourpi = 12.566370614359172;
+    // P_m^m upward in m; for each m run the l-recurrence and emit columns (l, +m) and (l, -m)
+    double pmm = 1.0;
+    for (int m = 0; m <= lmax; m++) {
+        if (m > 0) pmm *= (2 * m - 1) * st;      // no Condon-Shortley phase
+        const double cm = cos(m * phi), sm = sin(m * phi);
+        double p_lm2 = 0.0, p_lm1 = 0.0;
+        for (int l = m; l <= lmax; l++) {
+            double p;
+            if (l == m) p = pmm;
+            else if (l == m + 1) p = ct * (2 * m + 1) * pmm;
+            else p = ((2 * l - 1) * ct * p_lm1 - (l + m - 1) * p_lm2) / (l - m);
+            p_lm2 = p_lm1; p_lm1 = p;
+            // (l-m)!/(l+m)!
+            double ratio = 1.0;
+            for (int k = l - m + 1; k <= l + m; k++) ratio /= (double)k;
+            const double norm = sqrt((m == 0 ? 1.0 : 2.0) * (2 * l + 1) / fourpi * ratio);
+            const int base = l * l + l;          // column of (l, 0)
+            o[base + m] = (float)(norm * p * cm);
+            if (m > 0) o[base - m] = (float)(norm * p * sm);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sh_reconstruct_kernel(const float* __restrict__ basis, const float* __restrict__ coeff, float* __restrict__ out,
+                      int ns, int nb, int nc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)ns * nc) return;
+    const int s = (int)(i / nc), c = (int)(i % nc);
+    float acc = 0.f;
+    for (int b = 0; b < nb; b++) acc += basis[(size_t)s * nb + b] * coeff[b * nc + c];
+    out[i] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+sh_fit_kernel(const float* __restrict__ samples, const float* __restrict__ basis, float* __restrict__ out,
+              int ns, int nb, int nc) {
+    __shared__ float red[256];
+    const int o = blockIdx.x;            // output (b, c)
+    const int b = o / nc, c = o % nc;
+    float acc = 0.f;
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) acc += samples[(size_t)s * nc + c] * basis[(size_t)s * nb + b];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[o] = red[0] * (4.0f * RNR_PI_F / (float)ns);
+}
+
+__global__ void __launch_bounds__(256)
+interpolate_bilinear_kernel(const float* __restrict__ data, int h, int w, int c, const float* __restrict__ x,
+                            const float* __restrict__ y, float* __restrict__ out, int32_t* __restrict__ taps, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * c) return;
+    const int s = (int)(i / c), ch = (int)(i % c);
+    const Taps t = bilinear_taps(x[s], y[s], w, h);
+    const float v = data[((size_t)t.y0 * w + t.x0) * c + ch] * t.w00 + data[((size_t)t.y1 * w + t.x0) * c + ch] * t.w10 +
+                    data[((size_t)t.y0 * w + t.x1) * c + ch] * t.w01 + data[((size_t)t.y1 * w + t.x1) * c + ch] * t.w11;
+    out[i] = v;
+    if (taps && ch == 0) {
+        taps[s * 4 + 0] = t.x0; taps[s * 4 + 1] = t.y0; taps[s * 4 + 2] = t.x1; taps[s * 4 + 3] = t.y1;
+    }
+}
+
+// ---- layout helpers --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int hw, int c_pad, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*hw*c_pad
+    if (i >= total) return;
+    const int ch = (int)(i % c_pad);
+    const long np = i / c_pad;
+    const long n = np / hw, p = np % hw;
+    out[i] = ch < c ? in[(n * c + ch) * hw + p] : 0.0f;
+}
+
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ bias,
+                    int apply_tanh, int c, int hw, int c_pad, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*c*hw (output order)
+    if (i >= total) return;
+    const long p = i % hw;
+    const long nc = i / hw;
+    const int ch = (int)(nc % c);
+    const long n = nc / c;
+    float v = in[(n * hw + p) * c_pad + ch];
+    if (bias) v += bias[ch];
+    if (apply_tanh) v = tanhf(v);
+    out[i] = v;
+}
+
+}  // namespace rnr
+
+using namespace rnr;
+
+extern "C" int rnr_project_vertices(const float* vertices, const float* K, const float* R, const float* t,
+                                    const float* dist_coeffs, const float* offset, const float* scale,
+                                    float* out, int num_views, int num_vertices, float orig_size, float eps,
+                                    void* stream) {
+    RNR_REQUIRE(vertices && K && R && t && out, "rnr_project_vertices: null pointer argument");
+    RNR_REQUIRE((offset == nullptr) == (scale == nullptr), "rnr_project_vertices: offset and scale go together");
+    RNR_REQUIRE(num_views > 0 && num_vertices > 0, "rnr_project_vertices: bad sizes");
+    const long total = (long)num_views * num_vertices;
+    hipLaunchKernelGGL(project_vertices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), vertices, K, R, t, dist_coeffs, offset, scale, out, num_views,
+                       num_vertices, orig_size, eps);
+    return check_launch("project_vertices_kernel");
+}
+
+extern "C" int rnr_face_tangents(const rnr_mesh* mesh, float* out, void* stream) {
+    RNR_REQUIRE(mesh && out && mesh->v && mesh->vt && mesh->f_v_idx && mesh->f_vt_idx && mesh->num_faces > 0,
+                "rnr_face_tangents: incomplete mesh");
+    hipLaunchKernelGGL(face_tangents_kernel, dim3((mesh->num_faces + 255) / 256), dim3(256), 0,
+                       as_stream(stream), *mesh, out);
+    return check_launch("face_tangents_kernel");
+}
+
+extern "C" int rnr_shade_inputs(const int32_t* face_index_map, const float* alpha, const float* uv_map,
+                                const float* normal_map, const float* face_tangents, int num_faces,
+                                const float* proj_inv, const float* R_inv, const float* const* textures_host,
+                                const int* tex_sizes_host, int num_levels, int tex_channels, int sh_start_ch,
+                                const rnr_rays* rays, float* net_in, int c_pad, float* rays_uv,
+                                float* neural_img, float* sh_basis_map, int num_views, int height, int width,
+                                void* stream) {
+    RNR_REQUIRE(face_index_map && alpha && uv_map && normal_map && face_tangents && proj_inv && R_inv &&
+                    textures_host && tex_sizes_host && rays && net_in,
+                "rnr_shade_inputs: null pointer argument");
+    RNR_REQUIRE(num_levels >= 1 && num_levels <= MAX_LEVELS, "rnr_shade_inputs: num_levels %d not in [1,%d]",
+                num_levels, MAX_LEVELS);
+    RNR_REQUIRE(tex_channels > 0 && tex_channels % 4 == 0, "rnr_shade_inputs: texture channels must be a multiple of 4");
+    RNR_REQUIRE(rays->num_spec >= 0 && rays->num_spec <= MAX_RAYS && rays->num_diff >= 0 && rays->num_diff <= MAX_RAYS,
+                "rnr_shade_inputs: at most %d rays per sampler", MAX_RAYS);
+    const int c_in = 3 * (rays->num_spec + rays->num_diff) + 6 + tex_channels;
+    RNR_REQUIRE(c_pad >= c_in && c_pad % 4 == 0, "rnr_shade_inputs: c_pad %d < %d or not a multiple of 4", c_pad, c_in);
+    RNR_REQUIRE((3 * (rays->num_spec + rays->num_diff) + 6) % 4 == 0,
+                "rnr_shade_inputs: 3*rays+6 must be a multiple of 4 (texture channels are written as float4)");
+    RNR_REQUIRE(sh_start_ch < 0 || sh_start_ch + 9 <= tex_channels, "rnr_shade_inputs: sh_start_ch + 9 > channels");
+    ShadeParams P = {};
+    P.face_index_map = face_index_map; P.alpha = alpha; P.uv_map = uv_map; P.normal_map = normal_map;
+    P.tangents = face_tangents; P.num_faces = num_faces; P.proj_inv = proj_inv; P.R_inv = R_inv;
+    for (int l = 0; l < num_levels; l++) {
+        RNR_REQUIRE(textures_host[l] && tex_sizes_host[l] >= 2, "rnr_shade_inputs: bad texture level %d", l);
+        P.tex[l] = textures_host[l];
+        P.tex_size[l] = tex_sizes_host[l];
+    }
+    P.num_levels = num_levels; P.C = tex_channels; P.sh_start = sh_start_ch;
+    P.n_spec = rays->num_spec; P.n_diff = rays->num_diff;
+    for (int r = 0; r < rays->num_spec; r++)
+        for (int k = 0; k < 3; k++) P.piv_spec[r * 3 + k] = rays->pivots_spec_host[k * rays->num_spec + r];
+    for (int r = 0; r < rays->num_diff; r++)
+        for (int k = 0; k < 3; k++) P.piv_diff[r * 3 + k] = rays->pivots_diff_host[k * rays->num_diff + r];
+    P.net_in = net_in; P.c_pad = c_pad; P.rays_uv = rays_uv; P.neural_img = neural_img; P.sh_basis_map = sh_basis_map;
+    P.npix = (long)num_views * height * width; P.H = height; P.W = width;
+    const size_t lds = (size_t)(SH_PIX * c_pad + SH_PIX * GEO) * sizeof(float);
+    RNR_REQUIRE(lds <= 160 * 1024, "rnr_shade_inputs: c_pad too large for LDS");
+    const unsigned blocks = (unsigned)((P.npix + SH_PIX - 1) / SH_PIX);
+    hipLaunchKernelGGL(shade_inputs_kernel, dim3(blocks), dim3(SH_THREADS), lds, as_stream(stream), P);
+    return check_launch("shade_inputs_kernel");
+}
+
+extern "C" int rnr_ray_render(const float* unet_raw, int c_out_pad, const float* bias, const float* net_in,
+                              int c_pad, const float* alpha, const float* lp, int lp_h, int lp_w, int num_spec,
+                              int num_diff, int albedo_diff_ch, int albedo_spec_ch, float* image, int num_views,
+                              int height, int width, void* stream) {
+    RNR_REQUIRE(unet_raw && bias && net_in && alpha && lp && image, "rnr_ray_render: null pointer argument");
+    RNR_REQUIRE(num_spec >= 1 && num_spec <= 16 && num_diff >= 0 && num_diff <= 16,
+                "rnr_ray_render: ray counts must be <= 16 per group (got %d, %d)", num_spec, num_diff);
+    RNR_REQUIRE(lp_h >= 2 && lp_w >= 2, "rnr_ray_render: bad light-probe size");
+    RayParams P;
+    P.unet_raw = unet_raw; P.c_out_pad = c_out_pad; P.bias = bias; P.net_in = net_in; P.c_pad = c_pad;
+    P.alpha = alpha; P.lp = lp; P.lp_h = lp_h; P.lp_w = lp_w; P.n_spec = num_spec; P.n_diff = num_diff;
+    P.alb_diff_ch = albedo_diff_ch; P.alb_spec_ch = albedo_spec_ch; P.image = image;
+    P.npix = (long)num_views * height * width; P.hw = height * width;
+    const long lanes = P.npix * 32;
+    hipLaunchKernelGGL(ray_render_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, as_stream(stream), P);
+    return check_launch("ray_render_kernel");
+}
+
+extern "C" int rnr_sh_basis(const float* dirs, float* out, int n, int lmax, void* stream) {
+    RNR_REQUIRE(dirs && out && n > 0, "rnr_sh_basis: bad arguments");
+    RNR_REQUIRE(lmax >= 0 && lmax <= SH_LMAX_MAX, "rnr_sh_basis: lmax %d not in [0,%d]", lmax, SH_LMAX_MAX);
+    hipLaunchKernelGGL(sh_basis_kernel, dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), dirs, out, n, lmax);
+    return check_launch("sh_basis_kernel");
+}
+
+extern "C" int rnr_sh_reconstruct(const float* basis, const float* coeff, float* out, int num_samples,
+                                  int num_basis, int num_channels, void* stream) {
+    RNR_REQUIRE(basis && coeff && out && num_samples > 0 && num_basis > 0 && num_channels > 0,
+                "rnr_sh_reconstruct: bad arguments");
+    const long total = (long)num_samples * num_channels;
+    hipLaunchKernelGGL(sh_reconstruct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), basis, coeff, out, num_samples, num_basis, num_channels);
+    return check_launch("sh_reconstruct_kernel");
+}
+
+extern "C" int rnr_sh_fit(const float* samples, const float* basis, float* out, int num_samples, int num_basis,
+                          int num_channels, void* stream) {
+    RNR_REQUIRE(samples && basis && out && num_samples > 0 && num_basis > 0 && num_channels > 0,
+                "rnr_sh_fit: bad arguments");
+    hipLaunchKernelGGL(sh_fit_kernel, dim3(num_basis * num_channels), dim3(256), 0, as_stream(stream), samples,
+                       basis, out, num_samples, num_basis, num_channels);
+    return check_launch("sh_fit_kernel");
+}
+
+extern "C" int rnr_interpolate_bilinear(const float* data, int h, int w, int c, const float* x, const float* y,
+                                        float* out, int32_t* taps, int n, void* stream) {
+    RNR_REQUIRE(data && x && y && out && h > 0 && w > 0 && c > 0 && n > 0, "rnr_interpolate_bilinear: bad arguments");
+    const long total = (long)n * c;
+    hipLaunchKernelGGL(interpolate_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), data, h, w, c, x, y, out, taps, n);
+    return check_launch("interpolate_bilinear_kernel");
+}
+
+extern "C" int rnr_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream) {
+    RNR_REQUIRE(in && out && n > 0 && c > 0 && c_pad >= c, "rnr_nchw_to_nhwc: bad arguments");
+    const long total = (long)n * h * w * c_pad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       in, out, c, h * w, c_pad, total);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int rnr_nhwc_to_nchw(const float* in, float* out, const float* bias, int apply_tanh, int n, int c,
+                                int h, int w, int c_pad, void* stream) {
+    RNR_REQUIRE(in && out && n > 0 && c > 0 && c_pad >= c, "rnr_nhwc_to_nchw: bad arguments");
+    const long total = (long)n * c * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       in, out, bias, apply_tanh, c, h * w, c_pad, total);
+    return check_launch("nhwc_to_nchw_kernel");
+}

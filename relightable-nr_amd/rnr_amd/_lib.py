@@ -1,0 +1,108 @@
+"""ctypes binding of librnr_hip.so (the C ABI declared in include/rnr_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing or a symbol
+cannot be resolved this module raises — callers never silently route elsewhere.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'librnr_hip.so')
+
+c_void_p, c_int, c_float, c_size_t, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
+                                                ctypes.c_double)
+
+
+class RnrMesh(ctypes.Structure):
+    _fields_ = [('v', c_void_p), ('vt', c_void_p), ('vn', c_void_p), ('f_v_idx', c_void_p),
+                ('f_vt_idx', c_void_p), ('f_vn_idx', c_void_p), ('num_vertices', c_int),
+                ('num_texcoords', c_int), ('num_normals', c_int), ('num_faces', c_int)]
+
+
+class RnrGbuffer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ['face_index_map', 'alpha', 'depth', 'weight_map', 'raw_weight_map',
+                                        'uv_map', 'normal_map', 'normal_map_cam', 'position_map',
+                                        'position_map_cam']]
+
+
+class RnrRays(ctypes.Structure):
+    _fields_ = [('pivots_spec_host', c_void_p), ('pivots_diff_host', c_void_p), ('num_spec', c_int),
+                ('num_diff', c_int)]
+
+
+class RnrConvSrc(ctypes.Structure):
+    _fields_ = [('data', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('channels', c_int), ('act', c_int)]
+
+
+class RnrConvDesc(ctypes.Structure):
+    _fields_ = [('kind', c_int), ('c_in0', c_int), ('c_in0_pad', c_int), ('c_in1', c_int), ('c_in1_pad', c_int),
+                ('c_out', c_int), ('c_out_pad', c_int)]
+
+
+ACT_NONE, ACT_LRELU02, ACT_RELU = 0, 1, 2
+CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2 = 0, 1, 2
+
+P = ctypes.POINTER
+# name -> (restype, argtypes); must list every symbol of include/rnr_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    'rnr_abi_version': (c_int, []),
+    'rnr_last_error': (ctypes.c_char_p, []),
+    'rnr_raster_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'rnr_forward_face_index_map': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int,
+                                                            c_int, c_void_p, c_void_p]),
+    'rnr_forward_texture_sampling': (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    'rnr_project_vertices': (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_void_p]),
+    'rnr_gbuffer_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'rnr_rasterize_gbuffer': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_float, P(RnrGbuffer),
+                                      c_void_p, c_void_p]),
+    'rnr_face_tangents': (c_int, [P(RnrMesh), c_void_p, c_void_p]),
+    'rnr_shade_inputs': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, P(c_void_p), P(c_int), c_int, c_int,
+                                                  c_int, P(RnrRays), c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                  c_int, c_int, c_int, c_void_p]),
+    'rnr_packed_weight_floats': (c_size_t, [P(RnrConvDesc)]),
+    'rnr_pack_conv_weight': (c_int, [P(RnrConvDesc), c_void_p, c_void_p, c_void_p]),
+    'rnr_conv_workspace_bytes': (c_size_t, [P(RnrConvDesc), c_int, c_int, c_int]),
+    'rnr_conv2d': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
+                           c_int, c_void_p, c_size_t, c_void_p]),
+    'rnr_bn_finalize': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
+    'rnr_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rnr_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rnr_ray_render': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_sh_basis': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rnr_sh_reconstruct': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_sh_fit': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_interpolate_bilinear': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class RnrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librnr_hip.so (does not need a GPU; launching kernels does)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RnrError('librnr_hip.so not found at %s - build it first: `python -c "import __graft_entry__ as g; '
+                       'g.build()"` or `make -C relightable-nr_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.rnr_abi_version()
+    if ver != 1:
+        raise RnrError('librnr_hip.so ABI version %d, python binding expects 1' % ver)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RnrError(load().rnr_last_error().decode('utf-8', 'replace'))

@@ -1,0 +1,246 @@
+"""Operators of the hot path on torch device tensors, each a thin shim over one C-ABI entry point of
+librnr_hip.so.  torch is plumbing here (HBM allocation, the current HIP stream); every operator launches
+hand-written gfx950 kernels and raises if the library or a GPU is missing — there is no fallback.
+
+Argument checks mirror the reference extension's CHECK_INPUT (rasterize_cuda.cpp:66-68): device-resident,
+contiguous, right dtype, else RuntimeError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (RnrConvDesc, RnrConvSrc, RnrGbuffer, RnrMesh, RnrRays, check)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA (HIP) tensor' % name)
+    if not t.is_contiguous():
+        raise RuntimeError('%s must be contiguous' % name)
+    if t.dtype != dtype:
+        raise RuntimeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# neural_renderer.cuda.rasterize drop-ins
+# ---------------------------------------------------------------------------------------------------
+def forward_face_index_map(faces, face_index_map, weight_map, depth_map, face_inv_map, faces_inv, image_size, near,
+                           far, return_rgb, return_alpha, return_depth):
+    """rasterize_cuda.cpp:66-98.  In-place on the caller's pre-filled buffers; returns them."""
+    L = _lib.load()
+    _chk(faces, 'faces'); _chk(face_index_map, 'face_index_map', torch.int32); _chk(weight_map, 'weight_map')
+    _chk(depth_map, 'depth_map'); _chk(faces_inv, 'faces_inv')
+    if return_depth:
+        _chk(face_inv_map, 'face_inv_map')
+    B, nf = faces.shape[0], faces.shape[1]
+    ws = torch.empty(L.rnr_raster_workspace_bytes(B, nf), dtype=torch.uint8, device=faces.device)
+    check(L.rnr_forward_face_index_map(_ptr(faces), _ptr(face_index_map), _ptr(weight_map), _ptr(depth_map),
+                                       _ptr(face_inv_map if return_depth else None), _ptr(faces_inv), B, nf,
+                                       int(image_size), float(near), float(far), int(return_rgb), int(return_alpha),
+                                       int(return_depth), _ptr(ws), _stream()))
+    return [face_index_map, weight_map, depth_map, face_inv_map]
+
+
+def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_map, rgb_map, sampling_index_map,
+                             sampling_weight_map, image_size, eps):
+    """rasterize_cuda.cpp:100-122."""
+    L = _lib.load()
+    _chk(faces, 'faces'); _chk(textures, 'textures'); _chk(face_index_map, 'face_index_map', torch.int32)
+    _chk(weight_map, 'weight_map'); _chk(depth_map, 'depth_map'); _chk(rgb_map, 'rgb_map')
+    _chk(sampling_index_map, 'sampling_index_map', torch.int32); _chk(sampling_weight_map, 'sampling_weight_map')
+    B, nf = faces.shape[0], faces.shape[1]
+    check(L.rnr_forward_texture_sampling(_ptr(faces), _ptr(textures), _ptr(face_index_map), _ptr(weight_map),
+                                         _ptr(depth_map), _ptr(rgb_map), _ptr(sampling_index_map),
+                                         _ptr(sampling_weight_map), B, nf, int(image_size), int(textures.shape[2]),
+                                         float(eps), _stream()))
+    return [rgb_map, sampling_index_map, sampling_weight_map]
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused path
+# ---------------------------------------------------------------------------------------------------
+def project_vertices(vertices, K, R, t, orig_size, dist_coeffs=None, offset=None, scale=None, eps=1e-9):
+    """nr.projection for a shared mesh: vertices [nv,3], K/R [N,3,3], t [N,3] -> [N,nv,3]."""
+    L = _lib.load()
+    _chk(vertices, 'vertices'); _chk(K, 'K'); _chk(R, 'R'); _chk(t, 't')
+    N, nv = K.shape[0], vertices.shape[0]
+    out = torch.empty(N, nv, 3, dtype=torch.float32, device=vertices.device)
+    for x, n in ((dist_coeffs, 'dist_coeffs'), (offset, 'offset'), (scale, 'scale')):
+        if x is not None:
+            _chk(x, n)
+    check(L.rnr_project_vertices(_ptr(vertices), _ptr(K), _ptr(R), _ptr(t), _ptr(dist_coeffs), _ptr(offset),
+                                 _ptr(scale), _ptr(out), N, nv, float(orig_size), float(eps), _stream()))
+    return out
+
+
+class DeviceMesh:
+    """Mesh tensors resident in HBM + the ctypes struct the kernels take."""
+
+    def __init__(self, v, vt, vn, f_v_idx, f_vt_idx, f_vn_idx, device):
+        f = lambda x: torch.as_tensor(x, dtype=torch.float32).contiguous().to(device)
+        i = lambda x: torch.as_tensor(x, dtype=torch.int32).contiguous().to(device)
+        self.v, self.vt, self.vn = f(v), f(vt), f(vn)
+        self.f_v_idx, self.f_vt_idx, self.f_vn_idx = i(f_v_idx), i(f_vt_idx), i(f_vn_idx)
+        self.c = RnrMesh(self.v.data_ptr(), self.vt.data_ptr(), self.vn.data_ptr(), self.f_v_idx.data_ptr(),
+                         self.f_vt_idx.data_ptr(), self.f_vn_idx.data_ptr(), self.v.shape[0], self.vt.shape[0],
+                         self.vn.shape[0], self.f_v_idx.shape[0])
+        self.num_faces = self.f_v_idx.shape[0]
+        self.num_vertices = self.v.shape[0]
+        self._tangents = None
+
+    def tangents(self):
+        if self._tangents is None:
+            L = _lib.load()
+            out = torch.empty(self.num_faces, 3, dtype=torch.float32, device=self.v.device)
+            check(L.rnr_face_tangents(ctypes.byref(self.c), _ptr(out), _stream()))
+            self._tangents = out
+        return self._tangents
+
+
+GBUFFER_MAPS = {'face_index_map': (torch.int32, ()), 'alpha': (torch.float32, ()), 'depth': (torch.float32, ()),
+                'weight_map': (torch.float32, (3,)), 'raw_weight_map': (torch.float32, (3,)),
+                'uv_map': (torch.float32, (2,)), 'normal_map': (torch.float32, (3,)),
+                'normal_map_cam': (torch.float32, (3,)), 'position_map': (torch.float32, (3,)),
+                'position_map_cam': (torch.float32, (3,))}
+
+
+def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=None, out=None, workspace=None):
+    """network.Rasterizer.forward's per-pixel maps in one pass.  Returns dict name -> tensor [N,S,S(,k)]."""
+    L = _lib.load()
+    _chk(v_uvz, 'v_uvz')
+    N, S = v_uvz.shape[0], int(image_size)
+    maps = list(GBUFFER_MAPS) if maps is None else list(maps)
+    out = {} if out is None else out
+    for m in maps:
+        if m not in out:
+            dt, tail = GBUFFER_MAPS[m]
+            out[m] = torch.empty((N, S, S) + tail, dtype=dt, device=v_uvz.device)
+    gb = RnrGbuffer(*[out[m].data_ptr() if m in out else None for m in GBUFFER_MAPS])
+    if pose is not None:
+        _chk(pose, 'pose')
+    if workspace is None:
+        workspace = torch.empty(L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces), dtype=torch.uint8, device=v_uvz.device)
+    check(L.rnr_rasterize_gbuffer(ctypes.byref(mesh.c), _ptr(v_uvz), _ptr(pose), N, S, float(near), float(far),
+                                  ctypes.byref(gb), _ptr(workspace), _stream()))
+    return out
+
+
+def shade_inputs(gb, mesh, proj_inv, R_inv, textures, pivots_spec, pivots_diff, sh_start_ch, c_pad=None,
+                 want_rays_uv=False, want_neural_img=False, want_sh=False, net_in=None):
+    """G-buffer -> channel-last RenderingNet input [N,H,W,c_pad] (+ optional API copies).
+    textures: list of [1,S_l,S_l,C] or [S_l,S_l,C] device tensors; pivots_*: [3,R] CPU float tensors."""
+    L = _lib.load()
+    fim, alpha, uv, nrm = gb['face_index_map'], gb['alpha'], gb['uv_map'], gb['normal_map']
+    N, H, W = fim.shape
+    C = textures[0].shape[-1]
+    ns, nd = int(pivots_spec.shape[1]), int(pivots_diff.shape[1])
+    c_in = 3 * (ns + nd) + 6 + C
+    if c_pad is None:
+        c_pad = (c_in + 15) // 16 * 16
+    dev = fim.device
+    if net_in is None:
+        net_in = torch.empty(N, H, W, c_pad, dtype=torch.float32, device=dev)
+    rays_uv = torch.empty(N, H, W, 2, ns + nd, dtype=torch.float32, device=dev) if want_rays_uv else None
+    neural = torch.empty(N, C, H, W, dtype=torch.float32, device=dev) if want_neural_img else None
+    sh = torch.empty(N, H, W, 9, dtype=torch.float32, device=dev) if want_sh else None
+    nl = len(textures)
+    tex_ptrs = (ctypes.c_void_p * nl)(*[_chk(t, 'texture').data_ptr() for t in textures])
+    tex_sizes = (ctypes.c_int * nl)(*[int(t.shape[-2]) for t in textures])
+    ps = pivots_spec.detach().cpu().contiguous().float()
+    pd = pivots_diff.detach().cpu().contiguous().float()
+    rays = RnrRays(ps.data_ptr(), pd.data_ptr(), ns, nd)
+    check(L.rnr_shade_inputs(_ptr(_chk(fim, 'face_index_map', torch.int32)), _ptr(_chk(alpha, 'alpha')),
+                             _ptr(_chk(uv, 'uv_map')), _ptr(_chk(nrm, 'normal_map')), _ptr(mesh.tangents()),
+                             mesh.num_faces, _ptr(_chk(proj_inv, 'proj_inv')), _ptr(_chk(R_inv, 'R_inv')), tex_ptrs,
+                             tex_sizes, nl, C, int(sh_start_ch), ctypes.byref(rays), _ptr(net_in), c_pad,
+                             _ptr(rays_uv), _ptr(neural), _ptr(sh), N, H, W, _stream()))
+    return {'net_in': net_in, 'rays_uv': rays_uv, 'neural_img': neural, 'sh_basis_map': sh, 'c_pad': c_pad}
+
+
+def ray_render(unet_raw, bias, net_in, alpha, lp, num_spec, num_diff, albedo_diff_ch=0, albedo_spec_ch=3, image=None):
+    """bias+tanh + rays_lt scaling + RayRenderer.forward (seperate_albedo=True) -> [N,3,H,W]."""
+    L = _lib.load()
+    N, H, W, cop = unet_raw.shape
+    if image is None:
+        image = torch.empty(N, 3, H, W, dtype=torch.float32, device=unet_raw.device)
+    lp3 = lp.reshape(lp.shape[-3], lp.shape[-2], 3)
+    check(L.rnr_ray_render(_ptr(_chk(unet_raw, 'unet_raw')), cop, _ptr(_chk(bias, 'bias')), _ptr(_chk(net_in, 'net_in')),
+                           net_in.shape[-1], _ptr(_chk(alpha, 'alpha')), _ptr(_chk(lp3, 'lp')), lp3.shape[0],
+                           lp3.shape[1], int(num_spec), int(num_diff), int(albedo_diff_ch), int(albedo_spec_ch),
+                           _ptr(image), N, H, W, _stream()))
+    return image
+
+
+def sh_basis(dirs, lmax):
+    """sph_harm.evaluate_sh_basis: dirs [n,3] -> [n,(lmax+1)^2] float32."""
+    L = _lib.load()
+    _chk(dirs, 'dirs')
+    out = torch.empty(dirs.shape[0], (lmax + 1) ** 2, dtype=torch.float32, device=dirs.device)
+    check(L.rnr_sh_basis(_ptr(dirs), _ptr(out), dirs.shape[0], int(lmax), _stream()))
+    return out
+
+
+def sh_reconstruct(basis, coeff):
+    """sph_harm.reconstruct_sh for coeff [nb,C]: -> [ns,C]."""
+    L = _lib.load()
+    _chk(basis, 'basis'); _chk(coeff, 'coeff')
+    out = torch.empty(basis.shape[0], coeff.shape[1], dtype=torch.float32, device=basis.device)
+    check(L.rnr_sh_reconstruct(_ptr(basis), _ptr(coeff), _ptr(out), basis.shape[0], basis.shape[1], coeff.shape[1],
+                               _stream()))
+    return out
+
+
+def sh_fit(samples, basis):
+    """sph_harm.fit_sh_coeff for samples [ns,C]: -> [nb,C]."""
+    L = _lib.load()
+    _chk(samples, 'samples'); _chk(basis, 'basis')
+    out = torch.empty(basis.shape[1], samples.shape[1], dtype=torch.float32, device=basis.device)
+    check(L.rnr_sh_fit(_ptr(samples), _ptr(basis), _ptr(out), samples.shape[0], basis.shape[1], samples.shape[1],
+                       _stream()))
+    return out
+
+
+def interpolate_bilinear(data, x, y, want_taps=False):
+    """misc.interpolate_bilinear: data [H,W,C], x/y [...] -> [...,C] (+ int32 taps [...,4])."""
+    L = _lib.load()
+    _chk(data, 'data')
+    shp = x.shape
+    xf, yf = x.reshape(-1).contiguous(), y.reshape(-1).contiguous()
+    _chk(xf, 'x'); _chk(yf, 'y')
+    n, c = xf.shape[0], data.shape[2]
+    out = torch.empty(n, c, dtype=torch.float32, device=data.device)
+    taps = torch.empty(n, 4, dtype=torch.int32, device=data.device) if want_taps else None
+    check(L.rnr_interpolate_bilinear(_ptr(data), data.shape[0], data.shape[1], c, _ptr(xf), _ptr(yf), _ptr(out),
+                                     _ptr(taps), n, _stream()))
+    out = out.reshape(*shp, c)
+    return (out, taps.reshape(*shp, 4)) if want_taps else out
+
+
+def nchw_to_nhwc(x, c_pad):
+    L = _lib.load()
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    out = torch.empty(n, h, w, c_pad, dtype=torch.float32, device=x.device)
+    check(L.rnr_nchw_to_nhwc(_ptr(x), _ptr(out), n, c, h, w, c_pad, _stream()))
+    return out
+
+
+def nhwc_to_nchw(x, c, bias=None, apply_tanh=False):
+    L = _lib.load()
+    _chk(x, 'x')
+    n, h, w, c_pad = x.shape
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    check(L.rnr_nhwc_to_nchw(_ptr(x), _ptr(out), _ptr(bias), int(apply_tanh), n, c, h, w, c_pad, _stream()))
+    return out

@@ -1,0 +1,88 @@
+"""The per-view hot path of test_rnr.py:265-377 as one object: camera poses in, rendered frames out, every stage a
+hand-written gfx950 kernel launched on the current HIP stream.
+
+    projection -> face setup -> tiled z-resolve + attribute interpolation      (raster.hip)
+    -> TBN / view dir / SH9 / 4-level neural texture / 26 rays -> net input     (shade.hip)
+    -> 22 implicit-GEMM MFMA convolutions with fused train-mode BatchNorm      (conv.hip)
+    -> bias + tanh + light-transport x env-map ray renderer                     (shade.hip)
+
+Views are independent (BatchNorm statistics are per view), so a batch of N poses is just N frames.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .unet import UNetPlan
+
+
+class RNRPipeline:
+    def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
+                 sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None):
+        """
+        mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
+              network.Rasterizer.__init__ does, network.py:126-128)
+        textures: list of [1,S_l,S_l,C] tensors (TextureMapper.textures, network.py:43-57)
+        unet_state_dict: RenderingNet.state_dict() of the reference (keys `net.*`)
+        pivots_spec / pivots_diff: RaySampler.pivots_dir buffers [3,R]
+        lp: environment map [1,Hl,Wl,3] or [Hl,Wl,3] (LightingSH.reconstruct_lp output)
+        """
+        self.dev = torch.device(device)
+        self.S = int(img_size)
+        self.near, self.far = float(near), float(far)
+        v = torch.as_tensor(mesh['v'], dtype=torch.float32)
+        vn = torch.as_tensor(mesh['vn'], dtype=torch.float32)
+        if global_RT is not None:
+            g = torch.as_tensor(global_RT, dtype=torch.float32)
+            v = torch.matmul(g, torch.cat((v, torch.ones(v.shape[0], 1)), 1).t()).t()[:, :3]
+            vn = torch.nn.functional.normalize(torch.matmul(g[:3, :3], vn.t()).t(), dim=1)
+        self.mesh = ops.DeviceMesh(v, mesh['vt'], vn, mesh['f_v_idx'], mesh['f_vt_idx'], mesh['f_vn_idx'], self.dev)
+        self.textures = [torch.as_tensor(t, dtype=torch.float32).reshape(t.shape[-3], t.shape[-2], t.shape[-1])
+                         .contiguous().to(self.dev) for t in textures]
+        self.C = self.textures[0].shape[-1]
+        self.pivots_spec = torch.as_tensor(pivots_spec, dtype=torch.float32).cpu().contiguous()
+        self.pivots_diff = torch.as_tensor(pivots_diff, dtype=torch.float32).cpu().contiguous()
+        self.n_spec, self.n_diff = self.pivots_spec.shape[1], self.pivots_diff.shape[1]
+        self.sh_start_ch = int(sh_start_ch)
+        self.c_in = 3 * (self.n_spec + self.n_diff) + 6 + self.C
+        self.max_views = int(max_views)
+        self.unet = UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
+                             (self.S, self.S), self.max_views, self.dev)
+        self.set_light_probe(lp)
+        N, S = self.max_views, self.S
+        self._gb = {}
+        self._gb_maps = ['face_index_map', 'alpha', 'uv_map', 'normal_map']
+        self._net_in = torch.empty(N, S, S, self.unet.in_c_pad, dtype=torch.float32, device=self.dev)
+        self._image = torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev)
+        self._ws = torch.empty(ops._lib.load().rnr_gbuffer_workspace_bytes(N, self.mesh.num_faces), dtype=torch.uint8,
+                               device=self.dev)
+        for m in self._gb_maps:
+            dt, tail = ops.GBUFFER_MAPS[m]
+            self._gb[m] = torch.empty((N, S, S) + tail, dtype=dt, device=self.dev)
+        self.mesh.tangents()
+        self.last = {}
+
+    def set_light_probe(self, lp):
+        lp = torch.as_tensor(lp, dtype=torch.float32)
+        self.lp = lp.reshape(lp.shape[-3], lp.shape[-2], 3).contiguous().to(self.dev)
+
+    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False):
+        """proj/proj_inv/R_inv [N,3,3], pose [N,4,4] device float32 -> image [N,3,S,S] (a view into a reused buffer)."""
+        N = proj.shape[0]
+        if N > self.max_views:
+            raise RuntimeError('pipeline built for max_views=%d, got %d poses' % (self.max_views, N))
+        proj, pose = proj.contiguous(), pose.contiguous()
+        R = pose[:, :3, :3].contiguous()
+        t = pose[:, :3, 3].contiguous()
+        v_uvz = ops.project_vertices(self.mesh.v, proj, R, t, self.S)
+        gb = {m: self._gb[m][:N] for m in self._gb_maps}
+        ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
+                              workspace=self._ws)
+        sh = ops.shade_inputs(gb, self.mesh, proj_inv.contiguous(), R_inv.contiguous(), self.textures,
+                              self.pivots_spec, self.pivots_diff, self.sh_start_ch, c_pad=self.unet.in_c_pad,
+                              net_in=self._net_in[:N])
+        raw = self.unet.forward(sh['net_in'], N)
+        img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], self.lp, self.n_spec, self.n_diff,
+                             albedo_diff_ch=0, albedo_spec_ch=3, image=self._image[:N])
+        if keep_intermediates:
+            self.last = {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}
+        return img

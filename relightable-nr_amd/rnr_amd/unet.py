@@ -1,0 +1,155 @@
+"""RenderingNet's U-Net (network.py:219-253, pytorch_prototyping.py:370-536) as a static plan of
+rnr_conv2d / rnr_bn_finalize launches on channel-last HBM tensors.
+
+Built from a reference state-dict (strict key names).  Only the LIVE path is planned:
+`UnetSkipConnectionBlock.forward` recomputes `y` under `if self.flag_outer:` after the `if self.gcn:` branch
+(pytorch_prototyping.py:407-419), so `fuse.*` weights and `v_fea` never influence the output; they are accepted
+and ignored.  BatchNorm uses per-view batch statistics (the reference forces BN into train mode at inference,
+test_rnr.py:229-233, with N = 1 per call); Dropout2d is the identity in eval mode.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LRELU02, ACT_NONE, ACT_RELU, CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2, RnrConvDesc,
+                   RnrConvSrc, check)
+from .ops import _ptr, _stream
+
+
+def _pad16(c):
+    return (int(c) + 15) // 16 * 16
+
+
+class _Act:
+    """A raw conv output living in HBM plus the affine+activation its consumers must apply."""
+
+    def __init__(self, c, c_pad, h, w, act):
+        self.c, self.c_pad, self.h, self.w, self.act = c, c_pad, h, w, act
+        self.data = None      # [N,h,w,c_pad]
+        self.scale = None     # [N,c_pad] or None
+        self.shift = None
+
+
+class UNetPlan:
+    def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
+                 prefix='net.', in_c_pad=None):
+        self.L = _lib.load()
+        self.dev = device
+        self.N = int(max_views)
+        self.H, self.W = int(img_hw[0]), int(img_hw[1])
+        self.num_down = int(num_down)
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.in_c_pad = _pad16(in_channels) if in_c_pad is None else int(in_c_pad)
+        sd = {k: v for k, v in state_dict.items()}
+        g = lambda k: sd[prefix + k].detach().to(device=device, dtype=torch.float32).contiguous()
+        has = lambda k: (prefix + k) in sd
+        self.steps = []
+        self.ws_bytes = 256
+        self._keep = []
+
+        def conv_step(kind, srcs, wkey, bn_key, bias_key, act, c_out):
+            """srcs: list of _Act (1 or 2).  Returns the produced _Act."""
+            s0 = srcs[0]
+            s1 = srcs[1] if len(srcs) > 1 else None
+            desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
+            w = g(wkey)
+            packed = torch.empty(self.L.rnr_packed_weight_floats(ctypes.byref(desc)), dtype=torch.float32, device=device)
+            check(self.L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(w), _ptr(packed), _stream()))
+            if kind == CONV3x3_REFLECT:
+                oh, ow = s0.h, s0.w
+            elif kind == CONV4x4S2_REFLECT:
+                oh, ow = s0.h // 2, s0.w // 2
+            else:
+                oh, ow = s0.h * 2, s0.w * 2
+            out = _Act(c_out, desc.c_out_pad, oh, ow, act)
+            out.data = torch.empty(self.N, oh, ow, desc.c_out_pad, dtype=torch.float32, device=device)
+            step = {'desc': desc, 'packed': packed, 'srcs': srcs, 'out': out, 'in_hw': (s0.h, s0.w), 'bn': None}
+            if bn_key is not None and has(bn_key + '.weight'):
+                gamma, beta = g(bn_key + '.weight'), g(bn_key + '.bias')
+                out.scale = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
+                out.shift = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
+                step['bn'] = {'gamma': gamma, 'beta': beta,
+                              'stats': torch.zeros(self.N, desc.c_out_pad, 2, dtype=torch.float64, device=device)}
+            elif bias_key is not None and has(bias_key):
+                b = torch.zeros(desc.c_out_pad, dtype=torch.float32, device=device)
+                b[:c_out] = g(bias_key)
+                out.shift = b[None].repeat(self.N, 1).contiguous()
+                step['bias'] = b
+            self.ws_bytes = max(self.ws_bytes, self.L.rnr_conv_workspace_bytes(ctypes.byref(desc), self.N, s0.h, s0.w))
+            self.steps.append(step)
+            return out
+
+        # network input (already channel-last, no affine / activation)
+        x = _Act(self.in_channels, self.in_c_pad, self.H, self.W, ACT_NONE)
+        self.input = x
+        h = conv_step(CONV3x3_REFLECT, [x], 'in_layer.0.net.1.weight', 'in_layer.1', None, ACT_LRELU02, nf0)
+        max_c = 8 * nf0
+
+        def block(y, path, depth):
+            inner = min(2 ** (depth + 1) * nf0, max_c)
+            outer = y.c
+            d, u = path + 'down.net.', path + 'up.net.'
+            if depth == self.num_down - 1:      # innermost: norm=None => convs carry a bias (pytorch_prototyping.py:484-489)
+                inner = outer                   # both ends are min(2^(num_down-1) nf0, max) there
+                t = conv_step(CONV3x3_REFLECT, [y], d + '1.weight', None, d + '1.bias', ACT_LRELU02, outer)
+                t = conv_step(CONV4x4S2_REFLECT, [t], d + '5.weight', None, d + '5.bias', ACT_LRELU02, inner)
+                t = conv_step(CONVT4x4S2, [t], u + '0.weight', None, u + '0.bias', ACT_RELU, outer)
+                t = conv_step(CONV3x3_REFLECT, [t], u + '3.net.1.weight', None, u + '3.net.1.bias', ACT_RELU, outer)
+            else:
+                t = conv_step(CONV3x3_REFLECT, [y], d + '1.weight', d + '2', None, ACT_LRELU02, outer)
+                t = conv_step(CONV4x4S2_REFLECT, [t], d + '6.weight', d + '7', None, ACT_LRELU02, inner)
+                cat = block(t, path + 'submodule.', depth + 1)
+                t = conv_step(CONVT4x4S2, cat, u + '0.weight', u + '1', None, ACT_RELU, outer)
+                t = conv_step(CONV3x3_REFLECT, [t], u + '4.net.1.weight', u + '5', None, ACT_RELU, outer)
+            return [y, t]                       # torch.cat([x, y], 1) (pytorch_prototyping.py:429)
+
+        cat = block(h, 'unet_block.', 0)
+        out = conv_step(CONV3x3_REFLECT, cat, 'out_layer.0.net.1.weight', None, None, ACT_NONE, self.out_channels)
+        self.out = out
+        self.out_bias = torch.zeros(out.c_pad, dtype=torch.float32, device=device)
+        if has('out_layer.0.net.1.bias'):
+            self.out_bias[:self.out_channels] = g('out_layer.0.net.1.bias')
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.flops_per_view = self._count_flops()
+
+    def _count_flops(self):
+        total = 0
+        for s in self.steps:
+            d, (h, w) = s['desc'], s['in_hw']
+            cin = d.c_in0 + d.c_in1
+            if d.kind == CONV3x3_REFLECT:
+                total += 2 * h * w * 9 * cin * d.c_out
+            elif d.kind == CONV4x4S2_REFLECT:
+                total += 2 * (h // 2) * (w // 2) * 16 * cin * d.c_out
+            else:
+                total += 2 * (2 * h) * (2 * w) * 4 * cin * d.c_out
+        return total
+
+    def _src(self, a, n):
+        return RnrConvSrc(a.data.data_ptr(), a.scale.data_ptr() if a.scale is not None else None,
+                          a.shift.data_ptr() if a.shift is not None else None, a.c_pad, a.act)
+
+    def forward(self, net_in, n_views=None):
+        """net_in [n,H,W,in_c_pad] channel-last -> raw out-layer output [n,H,W,out_c_pad] (bias/tanh NOT applied)."""
+        n = net_in.shape[0] if n_views is None else n_views
+        if n > self.N:
+            raise RuntimeError('UNetPlan built for at most %d views, got %d' % (self.N, n))
+        if net_in.shape[-1] != self.in_c_pad or net_in.shape[1] != self.H or net_in.shape[2] != self.W:
+            raise RuntimeError('net_in shape %s does not match plan (H=%d W=%d c_pad=%d)' %
+                               (tuple(net_in.shape), self.H, self.W, self.in_c_pad))
+        self.input.data = net_in
+        L, st = self.L, _stream()
+        for s in self.steps:
+            srcs = s['srcs']
+            s0 = self._src(srcs[0], n)
+            s1 = self._src(srcs[1], n) if len(srcs) > 1 else None
+            out, bn = s['out'], s['bn']
+            h, w = s['in_hw']
+            check(L.rnr_conv2d(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
+                               _ptr(s['packed']), _ptr(out.data), _ptr(bn['stats']) if bn else None, n, h, w,
+                               _ptr(self.workspace), self.ws_bytes, st))
+            if bn:
+                check(L.rnr_bn_finalize(_ptr(bn['stats']), _ptr(bn['gamma']), _ptr(bn['beta']), _ptr(out.scale),
+                                        _ptr(out.shift), n, out.c, out.c_pad, float(out.h * out.w), 1e-5, st))
+        return self.out.data[:n]

@@ -1,0 +1,128 @@
+"""-m gpu: shading kernels vs the oracle / the reference golden vectors.
+Tolerances (float32 path): 2e-5 abs on O(1) quantities; integer tap indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def test_interpolate_bilinear_golden(golden):
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops
+    g = golden('bilinear')
+    out, taps = ops.interpolate_bilinear(T(g['data']).to(DEV), T(g['x']).to(DEV), T(g['y']).to(DEV), want_taps=True)
+    assert torch.allclose(out.cpu(), T(g['out']), atol=1e-6)
+    (x0, y0, x1, y1), _ = orc.bilinear_taps(g['data'].shape[0], g['data'].shape[1], T(g['x']), T(g['y']))
+    ref = torch.stack([x0, y0, x1, y1], -1).int()
+    assert torch.equal(taps.cpu(), ref)          # integer texel indices: bit-exact
+
+
+def test_sh_basis_vs_oracle():
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops, scene
+    d = scene.sphere_samples(4096)
+    d[:5] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 2, 0], [3, 4, 12]]      # poles, axes, non-unit
+    for lmax in (2, 10):
+        got = ops.sh_basis(T(d).to(DEV), lmax).cpu().numpy()
+        ref = orc.sh_basis(lmax, d)
+        assert np.abs(got - ref).max() < 2e-6, (lmax, np.abs(got - ref).max())
+
+
+def test_sh_linear_golden(golden):
+    from rnr_amd import ops
+    g = golden('sh_linear')
+    rec = ops.sh_reconstruct(T(g['basis']).to(DEV), T(g['coeff'][0]).to(DEV))
+    assert torch.allclose(rec.cpu(), T(g['recon2']), atol=1e-5)
+    fit = ops.sh_fit(T(g['samples'][0]).to(DEV), T(g['basis']).to(DEV))
+    assert torch.allclose(fit.cpu(), T(g['fit2']), atol=1e-5)
+
+
+def test_projection_golden(golden):
+    from rnr_amd import ops
+    g = golden('projection')
+    for b in range(g['vertices'].shape[0]):      # the kernel takes one shared mesh; run each batch element
+        a = lambda k: T(g[k][b:b + 1]).to(DEV)
+        out = ops.project_vertices(T(g['vertices'][b]).to(DEV), a('K'), a('R'), T(g['t'][b]).to(DEV), int(g['orig_size']))
+        assert torch.allclose(out.cpu()[0], T(g['out_nodist'][b]), atol=2e-5, rtol=1e-5)
+        out = ops.project_vertices(T(g['vertices'][b]).to(DEV), a('K'), a('R'), T(g['t'][b]).to(DEV), int(g['orig_size']),
+                                   dist_coeffs=a('dist'), offset=a('offset'), scale=a('scale'))
+        assert torch.allclose(out.cpu()[0], T(g['out_dist'][b]), atol=5e-5, rtol=2e-5)
+
+
+def _mesh_from_golden(gm):
+    from rnr_amd import ops
+    return ops.DeviceMesh(gm['buf_vertices'][0], gm['mesh_vt'], gm['buf_vertices_normals'][0], gm['mesh_f_v_idx'],
+                          gm['mesh_f_vt_idx'], gm['mesh_f_vn_idx'], DEV)
+
+
+def test_shade_inputs_vs_reference_frame(golden):
+    """G-buffer (reference's own) -> network input, compared with the reference's assembled render_net_input
+    (frame64, stored as fp16) and, tighter, with the oracle."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops, testing
+    gm, gf, gs = golden('rasterizer_module64'), golden('frame64'), golden('shading_geometry64')
+    mesh = _mesh_from_golden(gm)
+    tex = [T(gf['tex%d' % i]).to(DEV) for i in range(4)]
+    ps, pd = testing.ray_pivots(6, 2, 5), testing.ray_pivots(6, 2, 10)
+    for i in range(2):
+        gb = {'face_index_map': T(gm['view%d_face_index_map' % i]).to(DEV), 'alpha': T(gm['view%d_alpha' % i]).to(DEV),
+              'uv_map': T(gm['view%d_uv_map' % i]).to(DEV), 'normal_map': T(gm['view%d_normal_map' % i]).to(DEV)}
+        out = ops.shade_inputs(gb, mesh, T(gm['proj_inv'][i:i + 1]).to(DEV), T(gm['R_inv'][i:i + 1]).to(DEV), tex, ps, pd,
+                               6, want_rays_uv=True, want_neural_img=True, want_sh=True)
+        c_in = 26 * 3 + 6 + 16
+        net_in = out['net_in'][..., :c_in].permute(0, 3, 1, 2).cpu()
+        assert float(out['net_in'][..., c_in:].abs().max()) == 0.0
+        ref16 = T(gf['net_in'][i:i + 1]).float()
+        assert torch.allclose(net_in, ref16, atol=2e-3)
+        # oracle at full precision
+        gbo = {k: v.cpu() for k, v in gb.items()}
+        gbo['faces_v'] = T(gm['view%d_faces_v' % i])
+        gbo['faces_vt'] = T(gm['view%d_faces_vt' % i])
+        o = orc.shade_inputs(gbo, T(gm['proj_inv'][i:i + 1]), T(gm['R_inv'][i:i + 1]), [t.cpu()[None] for t in tex], ps, pd)
+        assert torch.allclose(net_in, o['net_in'], atol=2e-5), (net_in - o['net_in']).abs().max()
+        assert torch.allclose(out['sh_basis_map'].cpu(), o['sh_basis_map'], atol=2e-6)
+        assert torch.allclose(out['neural_img'].cpu(), o['neural_img'], atol=2e-5)
+        assert torch.allclose(out['rays_uv'].cpu(), o['rays_uv'], atol=2e-5)
+        if i == 0:   # reference-generated geometry of view 0
+            assert torch.allclose(out['rays_uv'].cpu()[..., :13], T(gs['rays_uv_spec']), atol=2e-5)
+            assert torch.allclose(out['rays_uv'].cpu()[..., 13:], T(gs['rays_uv_diff']), atol=2e-5)
+
+
+def test_ray_render_golden(golden):
+    """rnr_ray_render consumes ray DIRECTIONS (from net_in) and the raw out-layer output; build both from the golden
+    rays_uv / rays_lt by inverting the mappings, then compare with the reference RayRenderer output."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops
+    g = golden('ray_renderer')
+    uv, lt = T(g['rays_uv']), T(g['rays_lt'])               # [N,H,W,2,26], [N,26,3,H,W]
+    N, H, W, _, R = uv.shape
+    alpha = (uv[..., 0, 0] >= 0).float()                    # background pixels carry uv = -1
+    uvc = uv.clamp(min=1e-4, max=1 - 1e-4)
+    dirs = orc.spherical_mapping_inv(uvc.permute(3, 0, 1, 2, 4).reshape(2, -1)).reshape(3, N, H, W, R)
+    uv_back = orc.spherical_mapping(dirs, dim=0).permute(1, 2, 3, 0, 4) * alpha[..., None, None] - (alpha[..., None, None] == 0).float()
+    c_pad = 112
+    net_in = torch.zeros(N, H, W, c_pad)
+    net_in[..., :3 * R] = dirs.permute(1, 2, 3, 4, 0).reshape(N, H, W, 3 * R)
+    net_in[..., 84:87] = T(g['albedo_diffuse']).permute(0, 2, 3, 1)
+    net_in[..., 87:90] = T(g['albedo_specular']).permute(0, 2, 3, 1)
+    # rays_lt = (tanh(raw + bias)*0.5 + 0.5)*2  =>  raw = atanh(lt - 1) - bias
+    bias = torch.linspace(-0.2, 0.2, 80)
+    y = (lt - 1.0).clamp(-0.999, 0.999)
+    lt_eff = (y * 0.5 + 0.5) * 2.0
+    raw = torch.zeros(N, H, W, 80)
+    raw[..., :78] = torch.atanh(y).permute(0, 3, 4, 1, 2).reshape(N, H, W, 78) - bias[:78]
+    img = ops.ray_render(raw.to(DEV), bias.to(DEV), net_in.to(DEV), alpha.to(DEV), T(g['lp']).to(DEV), 13, 13)
+    ref = orc.ray_renderer(T(g['albedo_specular']), uv_back, lt_eff, T(g['lp']), albedo_diffuse=T(g['albedo_diffuse']),
+                           num_ray_diffuse=13, seperate_albedo=True)[0]
+    assert torch.allclose(img.cpu(), ref, atol=5e-4, rtol=1e-4), (img.cpu() - ref).abs().max()
+    # and the reference's own output where the uv round trip is harmless (interior uv only)
+    interior = ((uv > 2e-4) & (uv < 1 - 2e-4)).all(-1).all(-1) & (lt.permute(0, 3, 4, 1, 2).reshape(N, H, W, -1) < 1.99).all(-1) \
+        & (lt.permute(0, 3, 4, 1, 2).reshape(N, H, W, -1) > 0.01).all(-1)
+    d = (img.cpu() - T(g['out'])).abs().permute(0, 2, 3, 1)[interior]
+    assert d.numel() > 0 and d.max() < 2e-3, d.max()

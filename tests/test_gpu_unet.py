@@ -1,0 +1,155 @@
+"""-m gpu: MFMA implicit-GEMM convolutions and the U-Net plan vs plain PyTorch fp32 (F.conv2d etc. on CPU) and the
+reference golden vectors.  Tolerance: exact-fp32 MFMA vs CPU fp32 with a different summation order -> 1e-4 relative
+to the output scale per layer; 2e-4 abs on the tanh output of the whole net (PSNR > 70 dB)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def _act(x, a):
+    return F.leaky_relu(x, 0.2) if a == 1 else (F.relu(x) if a == 2 else x)
+
+
+def run_conv(kind, srcs, weight, c_out, N, H, W):
+    """srcs: list of (raw NCHW cpu tensor, scale [N,C] or None, shift [N,C] or None, act)."""
+    from rnr_amd import _lib
+    from rnr_amd.ops import _ptr, _stream
+    L = _lib.load()
+    pad16 = lambda c: (c + 15) // 16 * 16
+    keep, csrc, cs = [], [], []
+    for raw, sc, sh, act in srcs:
+        C = raw.shape[1]
+        cp = pad16(C)
+        d = torch.zeros(N, H, W, cp)
+        d[..., :C] = raw.permute(0, 2, 3, 1)
+        d = d.to(DEV)
+        scd = shd = None
+        if sc is not None:
+            scd = torch.zeros(N, cp); scd[:, :C] = sc; scd = scd.to(DEV)
+        if sh is not None:
+            shd = torch.zeros(N, cp); shd[:, :C] = sh; shd = shd.to(DEV)
+        keep += [d, scd, shd]
+        csrc.append(_lib.RnrConvSrc(d.data_ptr(), scd.data_ptr() if scd is not None else None,
+                                    shd.data_ptr() if shd is not None else None, cp, act))
+        cs.append((C, cp))
+    desc = _lib.RnrConvDesc(kind, cs[0][0], cs[0][1], cs[1][0] if len(cs) > 1 else 0, cs[1][1] if len(cs) > 1 else 0,
+                            c_out, pad16(c_out))
+    packed = torch.empty(L.rnr_packed_weight_floats(ctypes.byref(desc)), device=DEV)
+    wd = weight.contiguous().to(DEV)
+    _lib.check(L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(wd), _ptr(packed), _stream()))
+    oh, ow = (H, W) if kind == 0 else ((H // 2, W // 2) if kind == 1 else (2 * H, 2 * W))
+    out = torch.full((N, oh, ow, desc.c_out_pad), float('nan'), device=DEV)
+    stats = torch.zeros(N, desc.c_out_pad, 2, dtype=torch.float64, device=DEV)
+    wsb = L.rnr_conv_workspace_bytes(ctypes.byref(desc), N, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    _lib.check(L.rnr_conv2d(ctypes.byref(desc), ctypes.byref(csrc[0]), ctypes.byref(csrc[1]) if len(csrc) > 1 else None,
+                            _ptr(packed), _ptr(out), _ptr(stats), N, H, W, _ptr(ws), wsb, _stream()))
+    torch.cuda.synchronize()
+    return out.cpu(), stats.cpu()
+
+
+def ref_conv(kind, srcs, weight):
+    xs = []
+    for raw, sc, sh, act in srcs:
+        x = raw
+        if sc is not None:
+            x = x * sc[:, :, None, None]
+        if sh is not None:
+            x = x + sh[:, :, None, None]
+        xs.append(_act(x, act))
+    x = torch.cat(xs, 1).double()
+    w = weight.double()
+    if kind == 0:
+        return F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), w)
+    if kind == 1:
+        return F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), w, stride=2)
+    return F.conv_transpose2d(x, w, stride=2, padding=1)
+
+
+CASES = [
+    # kind, N, H, W, [C per source], c_out
+    (0, 1, 32, 32, [20], 16),          # padded channels both sides, cfg 256x64
+    (0, 2, 16, 24, [64], 78),          # cfg 256x96, non-square, 2 views
+    (0, 1, 16, 16, [64, 64], 128),     # skip concat, cfg 128x128
+    (1, 2, 16, 16, [32], 64),          # 4x4 stride 2
+    (1, 1, 32, 32, [64], 128),
+    (2, 1, 8, 8, [64, 64], 32),        # transposed conv, concat input
+    (2, 2, 4, 4, [512], 512),          # tiny map, deep K -> split-K + view-straddling tiles
+    (0, 3, 2, 2, [32], 32),            # 2x2 maps: reflect on both sides, tiles straddle views
+    (0, 1, 64, 64, [112], 64),         # first-layer-like
+]
+
+
+@pytest.mark.parametrize('kind,N,H,W,cins,c_out', CASES)
+def test_conv_vs_torch(kind, N, H, W, cins, c_out):
+    g = torch.Generator().manual_seed(kind * 100 + H + c_out)
+    srcs = []
+    for j, C in enumerate(cins):
+        raw = torch.randn(N, C, H, W, generator=g)
+        sc = torch.rand(N, C, generator=g) + 0.5 if j == 0 else None
+        sh = torch.randn(N, C, generator=g) * 0.3
+        srcs.append((raw, sc, sh, 1 if j == 0 else 2))
+    cin = sum(cins)
+    if kind == 2:
+        w = torch.randn(cin, c_out, 4, 4, generator=g) / (cin * 4) ** 0.5
+    else:
+        k = 3 if kind == 0 else 4
+        w = torch.randn(c_out, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    out, stats = run_conv(kind, srcs, w, c_out, N, H, W)
+    ref = ref_conv(kind, srcs, w).permute(0, 2, 3, 1)
+    got = out[..., :c_out].double()
+    assert torch.isfinite(out).all()
+    assert float(out[..., c_out:].abs().max() if out.shape[-1] > c_out else 0.0) == 0.0
+    scale = ref.abs().max()
+    assert (got - ref).abs().max() < 1e-4 * scale, ((got - ref).abs().max(), scale)
+    s1 = ref.sum(dim=(1, 2))
+    s2 = (ref * ref).sum(dim=(1, 2))
+    assert torch.allclose(stats[:, :c_out, 0], s1, rtol=1e-4, atol=1e-3 * float(scale) * H * W ** 0.5)
+    assert torch.allclose(stats[:, :c_out, 1], s2, rtol=1e-4)
+
+
+def _sd(g):
+    return {k[3:]: T(g[k]) for k in g.files if k.startswith('sd:')}
+
+
+@pytest.mark.parametrize('name,cin,cout,hw', [('unet_nf4', 10, 6, 64), ('unet_dnr_nf4', 7, 3, 32)])
+def test_unet_plan_golden(golden, name, cin, cout, hw):
+    from rnr_amd import ops
+    from rnr_amd.unet import UNetPlan
+    g = golden(name)
+    x = T(g['x'])
+    N = x.shape[0]
+    plan = UNetPlan(_sd(g), cin, cout, 4, 5, (hw, hw), N, torch.device(DEV))
+    raw = plan.forward(ops.nchw_to_nhwc(x.to(DEV), plan.in_c_pad))
+    y = ops.nhwc_to_nchw(raw, cout, bias=plan.out_bias, apply_tanh=True).cpu()
+    ref = T(g['y'])
+    assert (y - ref).abs().max() < 3e-4, (y - ref).abs().max()
+    # one view at a time must give the same numbers: statistics are per view
+    y0 = ops.nhwc_to_nchw(plan.forward(ops.nchw_to_nhwc(x[:1].to(DEV), plan.in_c_pad)), cout, bias=plan.out_bias,
+                          apply_tanh=True).cpu()
+    assert (y0 - y[:1]).abs().max() < 1e-5
+
+
+def test_unet_nf16_vs_oracle():
+    """Wider net (channels 16..128) at 128^2, 2 views: per-view statistics, every tile configuration."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops, testing
+    from rnr_amd.unet import UNetPlan
+    sd = testing.unet_state_dict(30, 78, 16, seed=3, out_channels_gcn=16)
+    x = torch.randn(2, 30, 128, 128, generator=torch.Generator().manual_seed(0))
+    plan = UNetPlan(sd, 30, 78, 16, 5, (128, 128), 2, torch.device(DEV))
+    raw = plan.forward(ops.nchw_to_nhwc(x.to(DEV), plan.in_c_pad))
+    y = ops.nhwc_to_nchw(raw, 78, bias=plan.out_bias, apply_tanh=True).cpu()
+    ref = orc.unet_forward(sd, x)
+    assert (y - ref).abs().max() < 5e-4, (y - ref).abs().max()
+    assert orc.psnr(y, ref, peak=2.0) > 70
