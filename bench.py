@@ -64,8 +64,13 @@ def cpu_baseline(sc, args, view_id, hip_image):
     from oracle import raster as oras
     from rnr_amd import scene
     oras.build()
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # more threads only oversubscribe the small torch-CPU ops
     torch.set_num_threads(cores)
+    try:
+        import ctypes
+        ctypes.CDLL('libgomp.so.1').omp_set_num_threads(cores)
+    except OSError:
+        pass
     views = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [view_id]).items()}
     mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
     t0 = time.time()

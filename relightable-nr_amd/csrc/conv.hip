@@ -493,7 +493,9 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
                 src0->channels, d->c_in0_pad);
     RNR_REQUIRE(d->c_in1_pad == 0 || (src1 && src1->data && src1->channels == d->c_in1_pad),
                 "rnr_conv2d: second source missing or channel mismatch");
-    RNR_REQUIRE(num_views > 0 && in_h >= 2 && in_w >= 2, "rnr_conv2d: bad sizes N=%d H=%d W=%d", num_views, in_h, in_w);
+    const int min_hw = d->kind == RNR_CONVT4x4S2 ? 1 : 2;   // ReflectionPad2d(1) needs >= 2 pixels
+    RNR_REQUIRE(num_views > 0 && in_h >= min_hw && in_w >= min_hw, "rnr_conv2d: bad sizes N=%d H=%d W=%d", num_views,
+                in_h, in_w);
     RNR_REQUIRE(d->kind != RNR_CONV4x4S2_REFLECT || (in_h % 2 == 0 && in_w % 2 == 0),
                 "rnr_conv2d: stride-2 conv needs even input size");
     hipStream_t st = as_stream(stream);

@@ -1,0 +1,33 @@
+"""Drop-in `neural_renderer` for MI355X: same names as the reference package
+(neural_renderer/neural_renderer/__init__.py:1-13) for the parts the relightable-nr scripts use
+(`nr.load_obj`, `nr.Renderer`, `nr.projection`, `nr.lighting`, `nr.vertices_to_faces`,
+`nr.vertex_attrs_to_faces`, `nr.rasterize_rgbad`, `nr.Rasterize`, ...), backed by librnr_hip.so.
+
+Out of scope: look / look_at / perspective camera modes, Mesh helper, save_obj, texture loading,
+and the backward kernels; those names raise NotImplementedError instead of silently misbehaving.
+"""
+from .lighting import lighting
+from .load_obj import load_obj
+from .projection import projection
+from .rasterize import (rasterize_rgbad, rasterize, rasterize_silhouettes, rasterize_depth, Rasterize)
+from .renderer import Renderer
+from .vertices_to_faces import vertices_to_faces
+from .vertices_to_faces import vertex_attrs_to_faces
+
+
+def _unsupported(name):
+    def f(*a, **k):
+        raise NotImplementedError('neural_renderer.%s is outside the MI355X hot-path build (SURVEY.md §2.1)' % name)
+    f.__name__ = name
+    return f
+
+
+get_points_from_angles = _unsupported('get_points_from_angles')
+look = _unsupported('look')
+look_at = _unsupported('look_at')
+perspective = _unsupported('perspective')
+save_obj = _unsupported('save_obj')
+Mesh = _unsupported('Mesh')
+
+__version__ = '1.1.3+rnr_hip'
+name = 'neural_renderer'
