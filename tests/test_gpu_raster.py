@@ -112,42 +112,54 @@ def test_argument_checks():
 
 
 def test_gbuffer_vs_reference_module(golden):
-    """Fused raster + interpolation vs network.Rasterizer.forward run from the reference's own Python.
-    (A) vertices projected by the oracle (bit-identical to the reference's projection): index map / alpha exact,
-        float maps to 2e-5;  (B) vertices projected by the HIP kernel: a few silhouette pixels may flip."""
+    """Fused raster + interpolation vs network.Rasterizer.forward.
+    (A) vs the oracle on THIS host, same projected vertices in: index map / alpha / raw weights / depth bit-exact,
+        interpolated maps to 2e-6 (different association of three-term sums only);
+    (B) vs the golden vectors produced by the reference's own Python in the build container: the projection there
+        went through a different CPU's matmul rounding, so silhouette slivers move by ~1e-4 in barycentrics and a
+        few pixels may flip: index mismatch < 0.2 %, smooth maps 1e-4, weights 5e-4."""
     from oracle import rnr_oracle as orc
     from rnr_amd import ops
     g = golden('rasterizer_module64')
     dev = 'cuda:0'
     mesh = ops.DeviceMesh(g['buf_vertices'][0], g['mesh_vt'], g['buf_vertices_normals'][0], g['mesh_f_v_idx'],
                           g['mesh_f_vt_idx'], g['mesh_f_vn_idx'], dev)
+    mesh_t = {k: torch.from_numpy(g['mesh_' + k]) for k in ['v', 'vt', 'vn', 'f_v_idx', 'f_vt_idx', 'f_vn_idx']}
+    mesh_t['v'], mesh_t['vn'] = torch.from_numpy(g['buf_vertices'][0]), torch.from_numpy(g['buf_vertices_normals'][0])
     S = int(g['image_size'])
     proj = torch.from_numpy(g['proj'])
     pose = torch.from_numpy(g['pose'])
-    # one view per call, like the reference (a batched matmul may round differently)
-    v_cpu = torch.cat([orc.projection(torch.from_numpy(g['buf_vertices']), proj[i:i + 1], pose[i:i + 1, :3, :3],
-                                      pose[i:i + 1, :3, 3][:, None, :], torch.zeros(1, 5), S) for i in range(2)])
+    for i in range(2):
+        o = orc.rasterizer_forward(mesh_t, proj[i:i + 1], pose[i:i + 1], S)
+        v_cpu = orc.projection(mesh_t['v'][None], proj[i:i + 1], pose[i:i + 1, :3, :3], pose[i:i + 1, :3, 3][:, None, :],
+                               torch.zeros(1, 5), S)
+        gb = ops.rasterize_gbuffer(mesh, v_cpu.contiguous().to(dev), pose[i:i + 1].to(dev), S)
+        torch.cuda.synchronize()
+        c = lambda k: gb[k][0].cpu()
+        assert torch.equal(c('face_index_map'), o['face_index_map'][0])
+        assert torch.equal(c('alpha'), o['alpha'][0])
+        assert np.array_equal(bits(c('raw_weight_map').numpy()), bits(o['raw_weight_map'][0].numpy()))
+        assert np.array_equal(bits(c('depth').numpy()), bits(o['depth'][0, ..., 0].numpy()))
+        for k in ['weight_map', 'uv_map', 'normal_map', 'normal_map_cam', 'position_map', 'position_map_cam']:
+            ref = o[k][0].reshape(c(k).shape)
+            d = (c(k) - ref).abs()
+            if k == 'uv_map':
+                d = torch.minimum(d, 1.0 - d)
+            assert d.max() < 2e-6 * max(1.0, float(ref.abs().max())), (k, d.max())
+        # (B) reference golden
+        ref_idx = g['view%d_face_index_map' % i][0]
+        mism = ref_idx != c('face_index_map').numpy()
+        assert mism.mean() < 2e-3, mism.sum()
+        ok = ~mism
+        for k, tol in [('uv_map', 1e-4), ('normal_map', 1e-4), ('position_map', 1e-4), ('depth', 1e-4), ('weight_map', 5e-4)]:
+            ref = g['view%d_%s' % (i, k)][0]
+            d = np.abs(c(k).numpy().reshape(ref.shape) - ref)[ok]
+            if k == 'uv_map':
+                d = np.minimum(d, 1.0 - d)
+            assert d.max() < tol * max(1.0, np.abs(ref[ok]).max()), (k, d.max())
+    # HIP projection kernel vs the oracle's (well-conditioned vertices)
     v_hip = ops.project_vertices(mesh.v, proj.to(dev), pose[:, :3, :3].contiguous().to(dev),
                                  pose[:, :3, 3].contiguous().to(dev), S)
-    assert torch.allclose(v_hip.cpu(), v_cpu, atol=1e-5, rtol=1e-5)
-    for tag, v_uvz in (('oracle-projected', v_cpu.contiguous().to(dev)), ('hip-projected', v_hip)):
-        gb = ops.rasterize_gbuffer(mesh, v_uvz, pose.to(dev), S)
-        torch.cuda.synchronize()
-        for i in range(2):
-            ref_idx = g['view%d_face_index_map' % i][0]
-            got_idx = gb['face_index_map'][i].cpu().numpy()
-            mism = (ref_idx != got_idx)
-            if tag == 'oracle-projected':
-                assert mism.sum() == 0, (tag, mism.sum())
-            assert mism.mean() < 2e-3, (tag, mism.sum())
-            ok = ~mism
-            assert np.array_equal(gb['alpha'][i].cpu().numpy()[ok], g['view%d_alpha' % i][0][ok])
-            tight = tag == 'oracle-projected'
-            for k, tol in [('uv_map', 2e-5), ('normal_map', 2e-5), ('normal_map_cam', 2e-5), ('position_map', 2e-5),
-                           ('position_map_cam', 5e-5), ('depth', 5e-5), ('weight_map', 2e-5 if tight else 5e-4)]:
-                ref = g['view%d_%s' % (i, k)][0]
-                got = gb[k][i].cpu().numpy().reshape(ref.shape)
-                d = np.abs(got - ref)[ok]
-                if k == 'uv_map':            # wrap-around at the seam: compare modulo 1
-                    d = np.minimum(d, 1.0 - d)
-                assert d.max() < tol * max(1.0, np.abs(ref[ok]).max()), (tag, k, d.max())
+    v_ref = torch.cat([orc.projection(mesh_t['v'][None], proj[i:i + 1], pose[i:i + 1, :3, :3],
+                                      pose[i:i + 1, :3, 3][:, None, :], torch.zeros(1, 5), S) for i in range(2)])
+    assert torch.allclose(v_hip.cpu(), v_ref, atol=5e-6, rtol=1e-5)

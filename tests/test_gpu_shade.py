@@ -58,9 +58,23 @@ def test_projection_golden(golden):
         out = ops.project_vertices(T(g['vertices'][b]).to(DEV), a('K'), a('R'), T(g['t'][b]).to(DEV), int(g['orig_size']),
                                    dist_coeffs=a('dist'), offset=a('offset'), scale=a('scale'))
         ref_d = T(g['out_dist'][b])
-        assert sane.float().mean() > 0.3
+        assert sane.sum() >= 8
         assert torch.allclose(out.cpu()[0][sane], ref_d[sane], atol=5e-5, rtol=2e-5)
         assert torch.allclose(out.cpu()[0][~sane], ref_d[~sane], atol=1e-3, rtol=1e-3)
+
+
+def test_projection_well_conditioned_vs_oracle():
+    """All vertices in front of the camera (the hot-path situation): 5e-6 abs on NDC coordinates in [-1,1]."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops, scene
+    mesh = scene.uv_sphere(32, 64)
+    v = scene.spiral_views(512, [0, 123, 700])
+    proj, pose = T(v['proj']), T(v['pose'])
+    ref = orc.projection(T(mesh['v'])[None].expand(3, -1, -1), proj, pose[:, :3, :3], pose[:, :3, 3][:, None, :],
+                         torch.zeros(1, 5), 512)
+    out = ops.project_vertices(T(mesh['v']).to(DEV), proj.to(DEV), pose[:, :3, :3].contiguous().to(DEV),
+                               pose[:, :3, 3].contiguous().to(DEV), 512)
+    assert (out.cpu() - ref).abs().max() < 5e-6
 
 
 def _mesh_from_golden(gm):
