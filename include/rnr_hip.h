@@ -242,6 +242,42 @@ int rnr_sh_fit(const float* samples, const float* basis, float* out, int num_sam
 int rnr_interpolate_bilinear(const float* data, int h, int w, int c, const float* x, const float* y,
                              float* out, int32_t* taps, int n, void* stream);
 
+/* =====================================================================================================
+ * 3. Stand-alone operators for the drop-in Python API (one reference function each).  The fused entry
+ *    points above compute the same quantities without the intermediate HBM round trips.
+ * ===================================================================================================== */
+
+/* camera.get_view_dir_map (camera.py:5-32): out_world/out_cam [N,H,W,3] (out_cam may be NULL). */
+int rnr_view_dir_map(const float* proj_inv, const float* R_inv, float* out_world, float* out_cam,
+                     int num_views, int height, int width, void* stream);
+
+/* render.get_TBN_map (render.py:152-166) given per-face unit tangents: out [N,H,W,3,3], columns (T,B,N). */
+int rnr_tbn_map(const float* normal_map, const int32_t* face_index_map, const float* face_tangents,
+                int num_faces, float* out, int num_views, int height, int width, void* stream);
+
+/* network.RaySampler.forward (network.py:445-472).  reflect != 0: mode 'reflect' (needs view_tangent), else the
+ * pivots themselves.  pivots_host [3,R] (HOST).  tbn [P,3,3], view_tangent [P,3], alpha [P];
+ * rays_dir [P,3,R], rays_uv [P,2,R], rays_dir_tangent [P,3,R] (reflect mode only; may be NULL). */
+int rnr_ray_sampler(int reflect, const float* pivots_host, int num_rays, const float* tbn,
+                    const float* view_tangent, const float* alpha, float* rays_dir, float* rays_uv,
+                    float* rays_dir_tangent, long num_pixels, void* stream);
+
+/* network.TextureMapper.forward (network.py:67-91) for any channel count: uv_map [N,H,W,2],
+ * sh_basis_map [N,H,W,9] or NULL, textures[level] [S_l,S_l,C] -> out [N,C,H,W]. */
+int rnr_texture_mapper(const float* uv_map, const float* sh_basis_map, const float* const* textures_host,
+                       const int* tex_sizes_host, int num_levels, int tex_channels, int sh_start_ch,
+                       float* out, int num_views, int height, int width, void* stream);
+
+/* network.RayRenderer.forward (network.py:481-527) on API-shaped tensors: rays_uv [N,H,W,2,R],
+ * rays_lt [N,R,C,H,W], lp [lp_n,Hl,Wl,C] (lp_n = 1 or N), albedos [N,C,H,W] (albedo_diffuse may be NULL).
+ * Outputs [N,C,H,W] (out required, others optional) and rays_color [N,R,C,H,W] (optional). */
+int rnr_ray_renderer(const float* rays_uv, const float* rays_lt, const float* lp, int lp_n, int lp_h,
+                     int lp_w, const float* albedo_specular, const float* albedo_diffuse, int channels,
+                     int num_rays, int num_ray_diffuse, int no_albedo, int seperate_albedo,
+                     float lp_scale_factor, float* out, float* out_specular, float* out_diffuse,
+                     float* ltt_specular, float* ltt_diffuse, float* rays_color, int num_views, int height,
+                     int width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

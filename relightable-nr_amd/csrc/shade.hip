@@ -484,6 +484,182 @@ interpolate_bilinear_kernel(const float* __restrict__ data, int h, int w, int c,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stand-alone operator kernels for the drop-in Python API (network.py / render.py / camera.py functions called one
+// at a time).  The fused pipeline does not use them: shade_inputs_kernel / ray_render_kernel compute the same
+// quantities without the HBM round trips.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+view_dir_map_kernel(const float* __restrict__ proj_inv, const float* __restrict__ R_inv, float* __restrict__ out_world,
+                    float* __restrict__ out_cam, long npix, int H, int W) {
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const int hw = H * W;
+    const int n = (int)(pix / hw), rem = (int)(pix % hw);
+    const int row = rem / W, col = rem % W;
+    const float* Pi = proj_inv + n * 9;
+    const float* Ri = R_inv + n * 9;
+    const float pu = (float)col + 0.5f, pv = (float)row + 0.5f;    // camera.py:19-20
+    float3 dc = f3(-(Pi[0] * pu + Pi[1] * pv + Pi[2]), -(Pi[3] * pu + Pi[4] * pv + Pi[5]),
+                   -(Pi[6] * pu + Pi[7] * pv + Pi[8]));
+    dc = normalize3(dc);
+    float3 vd = f3(Ri[0] * dc.x + Ri[1] * dc.y + Ri[2] * dc.z, Ri[3] * dc.x + Ri[4] * dc.y + Ri[5] * dc.z,
+                   Ri[6] * dc.x + Ri[7] * dc.y + Ri[8] * dc.z);
+    vd = normalize3(vd);
+    out_world[pix * 3 + 0] = vd.x; out_world[pix * 3 + 1] = vd.y; out_world[pix * 3 + 2] = vd.z;
+    if (out_cam) { out_cam[pix * 3 + 0] = dc.x; out_cam[pix * 3 + 1] = dc.y; out_cam[pix * 3 + 2] = dc.z; }
+}
+
+__global__ void __launch_bounds__(256)
+tbn_map_kernel(const float* __restrict__ normal_map, const int32_t* __restrict__ face_index_map,
+               const float* __restrict__ tangents, int num_faces, float* __restrict__ out, long npix) {
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    int fi = face_index_map[pix];
+    if (fi < 0) fi += num_faces;
+    const float3 tg = f3(tangents[fi * 3 + 0], tangents[fi * 3 + 1], tangents[fi * 3 + 2]);
+    const float3 nm = normalize3(f3(normal_map[pix * 3 + 0], normal_map[pix * 3 + 1], normal_map[pix * 3 + 2]));
+    const float3 bt = normalize3(cross3(nm, tg));
+    const float3 tt = normalize3(cross3(bt, nm));
+    float* o = out + pix * 9;      // [3,3] row-major, columns (T, B, N)  (render.py:164)
+    o[0] = tt.x; o[1] = bt.x; o[2] = nm.x;
+    o[3] = tt.y; o[4] = bt.y; o[5] = nm.y;
+    o[6] = tt.z; o[7] = bt.z; o[8] = nm.z;
+}
+
+struct RaySamplerParams {
+    const float* tbn; const float* view_tangent; const float* alpha;
+    float* rays_dir; float* rays_uv; float* rays_dir_tangent;
+    float piv[MAX_RAYS * 3];
+    int n_rays, reflect;
+    long npix;
+};
+
+__global__ void __launch_bounds__(256)
+ray_sampler_kernel(const RaySamplerParams P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.npix * P.n_rays) return;
+    const long pix = i / P.n_rays;
+    const int r = (int)(i % P.n_rays);
+    const float* M = P.tbn + pix * 9;
+    const float a = P.alpha[pix];
+    const float3 pv = f3(P.piv[r * 3 + 0], P.piv[r * 3 + 1], P.piv[r * 3 + 2]);
+    float3 lt;
+    if (P.reflect) {
+        const float3 v = f3(P.view_tangent[pix * 3 + 0], P.view_tangent[pix * 3 + 1], P.view_tangent[pix * 3 + 2]);
+        const float s = dot3(pv, v) * 2.0f;
+        lt = normalize3(f3(s * pv.x - v.x, s * pv.y - v.y, s * pv.z - v.z));
+        lt = f3(lt.x * a, lt.y * a, lt.z * a);
+    } else {
+        lt = pv;
+    }
+    float3 d = f3(M[0] * lt.x + M[1] * lt.y + M[2] * lt.z, M[3] * lt.x + M[4] * lt.y + M[5] * lt.z,
+                  M[6] * lt.x + M[7] * lt.y + M[8] * lt.z);
+    d = normalize3(d);
+    const int R = P.n_rays;
+    P.rays_dir[(pix * 3 + 0) * R + r] = d.x;
+    P.rays_dir[(pix * 3 + 1) * R + r] = d.y;
+    P.rays_dir[(pix * 3 + 2) * R + r] = d.z;
+    if (P.rays_dir_tangent) {
+        P.rays_dir_tangent[(pix * 3 + 0) * R + r] = lt.x;
+        P.rays_dir_tangent[(pix * 3 + 1) * R + r] = lt.y;
+        P.rays_dir_tangent[(pix * 3 + 2) * R + r] = lt.z;
+    }
+    float u = atan2f(d.z, d.x) * 0.5f / RNR_PI_F + 0.5f;
+    float v = acosf(d.y) * 1.0f / RNR_PI_F;
+    const float bg = (a == 0.0f) ? 1.0f : 0.0f;
+    P.rays_uv[(pix * 2 + 0) * R + r] = u * a - bg;
+    P.rays_uv[(pix * 2 + 1) * R + r] = v * a - bg;
+}
+
+struct TexMapParams {
+    const float* uv_map; const float* sh;   // sh may be NULL
+    const float* tex[MAX_LEVELS];
+    int tex_size[MAX_LEVELS];
+    int num_levels, C, sh_start;
+    float* out;                              // [N,C,H,W]
+    long npix; int hw;
+};
+
+// any channel count (DNR uses C = 30): one lane per (channel, pixel), pixel fastest so the NCHW store coalesces
+__global__ void __launch_bounds__(256)
+texture_mapper_kernel(const TexMapParams P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.npix * P.C) return;
+    const long n = i / ((long)P.C * P.hw);
+    const long rem = i % ((long)P.C * P.hw);
+    const int c = (int)(rem / P.hw);
+    const long p = rem % P.hw;
+    const long pix = n * P.hw + p;
+    const float u = P.uv_map[pix * 2 + 0], v = P.uv_map[pix * 2 + 1];
+    float acc = 0.f;
+    for (int l = 0; l < P.num_levels; l++) {
+        const int s = P.tex_size[l];
+        const float sm1 = (float)(s - 1);
+        const Taps t = bilinear_taps(u * sm1, sm1 - v * sm1, s, s);
+        const float* tex = P.tex[l];
+        const float lv = tex[((size_t)t.y0 * s + t.x0) * P.C + c] * t.w00 + tex[((size_t)t.y1 * s + t.x0) * P.C + c] * t.w10 +
+                         tex[((size_t)t.y0 * s + t.x1) * P.C + c] * t.w01 + tex[((size_t)t.y1 * s + t.x1) * P.C + c] * t.w11;
+        acc = (l == 0) ? lv : acc + lv;
+    }
+    if (P.sh && c >= P.sh_start && c < P.sh_start + 9) acc *= P.sh[pix * 9 + (c - P.sh_start)];
+    P.out[i] = acc;
+}
+
+// RayRenderer.forward with API-shaped inputs (network.py:481-527): one lane per (pixel, channel)
+struct RayApiParams {
+    const float* rays_uv;    // [N,H,W,2,R]
+    const float* rays_lt;    // [N,R,C,H,W]
+    const float* lp;         // [Nl,Hl,Wl,C], Nl = 1 or N
+    const float* alb_spec;   // [N,C,H,W]
+    const float* alb_diff;   // [N,C,H,W] or NULL
+    int lp_n, lp_h, lp_w, C, R, n_diff, no_albedo, separate;
+    float lp_scale;
+    float* out; float* out_spec; float* out_diff; float* ltt_spec; float* ltt_diff; float* rays_color;  // last may be NULL
+    long npix; int hw;
+};
+
+__global__ void __launch_bounds__(256)
+ray_renderer_api_kernel(const RayApiParams P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over N*C*hw
+    if (i >= P.npix * P.C) return;
+    const long n = i / ((long)P.C * P.hw);
+    const long rem = i % ((long)P.C * P.hw);
+    const int c = (int)(rem / P.hw);
+    const long p = rem % P.hw;
+    const long pix = n * P.hw + p;
+    const int n_spec = P.R - P.n_diff;
+    const float* lp = P.lp + (P.lp_n == 1 ? 0 : (size_t)n * P.lp_h * P.lp_w * P.C);
+    float ss = 0.f, sd = 0.f;
+    for (int r = 0; r < P.R; r++) {
+        const float u = P.rays_uv[(pix * 2 + 0) * P.R + r], v = P.rays_uv[(pix * 2 + 1) * P.R + r];
+        const float x = fminf(u * (float)P.lp_w, (float)(P.lp_w - 1));
+        const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
+        const Taps t = bilinear_taps(x, y, P.lp_w, P.lp_h);
+        const float col = (lp[((size_t)t.y0 * P.lp_w + t.x0) * P.C + c] * P.lp_scale) * t.w00 +
+                          (lp[((size_t)t.y1 * P.lp_w + t.x0) * P.C + c] * P.lp_scale) * t.w10 +
+                          (lp[((size_t)t.y0 * P.lp_w + t.x1) * P.C + c] * P.lp_scale) * t.w01 +
+                          (lp[((size_t)t.y1 * P.lp_w + t.x1) * P.C + c] * P.lp_scale) * t.w11;
+        const size_t li = (((size_t)n * P.R + r) * P.C + c) * P.hw + p;
+        if (P.rays_color) P.rays_color[li] = col;
+        const float prod = P.rays_lt[li] * col;
+        if (r < n_spec) ss += prod; else sd += prod;
+    }
+    const float ls = ss / (float)n_spec;
+    const float as = P.alb_spec[i];
+    const float os = P.no_albedo ? ls : as * ls;
+    float ld = 0.f, od = 0.f;
+    if (P.n_diff > 0) {
+        ld = sd / (float)P.n_diff;
+        od = P.no_albedo ? ld : ((P.separate && P.alb_diff) ? P.alb_diff[i] : as) * ld;
+    }
+    P.out[i] = os + od;
+    if (P.out_spec) P.out_spec[i] = os;
+    if (P.out_diff) P.out_diff[i] = od;
+    if (P.ltt_spec) P.ltt_spec[i] = ls;
+    if (P.ltt_diff) P.ltt_diff[i] = ld;
+}
+
 // ---- layout helpers --------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int hw, int c_pad, long total) {
@@ -647,4 +823,76 @@ extern "C" int rnr_nhwc_to_nchw(const float* in, float* out, const float* bias, 
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        in, out, bias, apply_tanh, c, h * w, c_pad, total);
     return check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int rnr_view_dir_map(const float* proj_inv, const float* R_inv, float* out_world, float* out_cam,
+                                int num_views, int height, int width, void* stream) {
+    RNR_REQUIRE(proj_inv && R_inv && out_world && num_views > 0 && height > 0 && width > 0, "rnr_view_dir_map: bad arguments");
+    const long npix = (long)num_views * height * width;
+    hipLaunchKernelGGL(view_dir_map_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       proj_inv, R_inv, out_world, out_cam, npix, height, width);
+    return check_launch("view_dir_map_kernel");
+}
+
+extern "C" int rnr_tbn_map(const float* normal_map, const int32_t* face_index_map, const float* face_tangents,
+                           int num_faces, float* out, int num_views, int height, int width, void* stream) {
+    RNR_REQUIRE(normal_map && face_index_map && face_tangents && out && num_faces > 0, "rnr_tbn_map: bad arguments");
+    const long npix = (long)num_views * height * width;
+    hipLaunchKernelGGL(tbn_map_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, as_stream(stream), normal_map,
+                       face_index_map, face_tangents, num_faces, out, npix);
+    return check_launch("tbn_map_kernel");
+}
+
+extern "C" int rnr_ray_sampler(int reflect, const float* pivots_host, int num_rays, const float* tbn,
+                               const float* view_tangent, const float* alpha, float* rays_dir, float* rays_uv,
+                               float* rays_dir_tangent, long num_pixels, void* stream) {
+    RNR_REQUIRE(pivots_host && tbn && alpha && rays_dir && rays_uv, "rnr_ray_sampler: null pointer argument");
+    RNR_REQUIRE(!reflect || view_tangent, "rnr_ray_sampler: reflect mode needs view_tangent");
+    RNR_REQUIRE(num_rays >= 1 && num_rays <= MAX_RAYS, "rnr_ray_sampler: 1..%d rays", MAX_RAYS);
+    RaySamplerParams P;
+    P.tbn = tbn; P.view_tangent = view_tangent; P.alpha = alpha; P.rays_dir = rays_dir; P.rays_uv = rays_uv;
+    P.rays_dir_tangent = reflect ? rays_dir_tangent : nullptr;
+    for (int r = 0; r < num_rays; r++)
+        for (int k = 0; k < 3; k++) P.piv[r * 3 + k] = pivots_host[k * num_rays + r];
+    P.n_rays = num_rays; P.reflect = reflect; P.npix = num_pixels;
+    const long total = num_pixels * num_rays;
+    hipLaunchKernelGGL(ray_sampler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), P);
+    return check_launch("ray_sampler_kernel");
+}
+
+extern "C" int rnr_texture_mapper(const float* uv_map, const float* sh_basis_map, const float* const* textures_host,
+                                  const int* tex_sizes_host, int num_levels, int tex_channels, int sh_start_ch,
+                                  float* out, int num_views, int height, int width, void* stream) {
+    RNR_REQUIRE(uv_map && textures_host && tex_sizes_host && out, "rnr_texture_mapper: null pointer argument");
+    RNR_REQUIRE(num_levels >= 1 && num_levels <= MAX_LEVELS && tex_channels > 0, "rnr_texture_mapper: bad sizes");
+    RNR_REQUIRE(!sh_basis_map || (sh_start_ch >= 0 && sh_start_ch + 9 <= tex_channels),
+                "rnr_texture_mapper: sh_start_ch + 9 > channels");
+    TexMapParams P = {};
+    P.uv_map = uv_map; P.sh = sh_basis_map;
+    for (int l = 0; l < num_levels; l++) { P.tex[l] = textures_host[l]; P.tex_size[l] = tex_sizes_host[l]; }
+    P.num_levels = num_levels; P.C = tex_channels; P.sh_start = sh_start_ch; P.out = out;
+    P.npix = (long)num_views * height * width; P.hw = height * width;
+    const long total = P.npix * tex_channels;
+    hipLaunchKernelGGL(texture_mapper_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), P);
+    return check_launch("texture_mapper_kernel");
+}
+
+extern "C" int rnr_ray_renderer(const float* rays_uv, const float* rays_lt, const float* lp, int lp_n, int lp_h,
+                                int lp_w, const float* albedo_specular, const float* albedo_diffuse, int channels,
+                                int num_rays, int num_ray_diffuse, int no_albedo, int seperate_albedo,
+                                float lp_scale_factor, float* out, float* out_specular, float* out_diffuse,
+                                float* ltt_specular, float* ltt_diffuse, float* rays_color, int num_views, int height,
+                                int width, void* stream) {
+    RNR_REQUIRE(rays_uv && rays_lt && lp && albedo_specular && out, "rnr_ray_renderer: null pointer argument");
+    RNR_REQUIRE(num_rays > num_ray_diffuse && num_ray_diffuse >= 0, "rnr_ray_renderer: bad ray counts");
+    RNR_REQUIRE(lp_n == 1 || lp_n == num_views, "rnr_ray_renderer: lp batch must be 1 or N");
+    RayApiParams P;
+    P.rays_uv = rays_uv; P.rays_lt = rays_lt; P.lp = lp; P.alb_spec = albedo_specular; P.alb_diff = albedo_diffuse;
+    P.lp_n = lp_n; P.lp_h = lp_h; P.lp_w = lp_w; P.C = channels; P.R = num_rays; P.n_diff = num_ray_diffuse;
+    P.no_albedo = no_albedo; P.separate = seperate_albedo; P.lp_scale = lp_scale_factor;
+    P.out = out; P.out_spec = out_specular; P.out_diff = out_diffuse; P.ltt_spec = ltt_specular; P.ltt_diff = ltt_diffuse;
+    P.rays_color = rays_color; P.npix = (long)num_views * height * width; P.hw = height * width;
+    const long total = P.npix * channels;
+    hipLaunchKernelGGL(ray_renderer_api_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), P);
+    return check_launch("ray_renderer_api_kernel");
 }

@@ -1,0 +1,276 @@
+"""Drop-in `network` (reference: network.py): the nn.Module classes test_rnr.py / test_dnr.py construct, with the same
+constructor / forward signatures, buffers and state-dict keys, computing on librnr_hip.so.
+
+In scope: TextureMapper, Rasterizer, RenderingNet, Interpolater, RaySampler, RayRenderer, LightingSH.
+Out of scope (raise on construction): DenseDeepGCN (train-time only; its cached output `v_feature` is loaded from the
+checkpoint and is dead at the output anyway), InterpolaterVertexAttr, Mesh, RaysLTChromLoss (loss), LightingLP (cv2).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+import neural_renderer as nr
+import camera
+import misc
+import render
+import sph_harm
+from pytorch_prototyping.pytorch_prototyping import *  # noqa: F401,F403  (the reference does the same, network.py:10)
+from pytorch_prototyping.pytorch_prototyping import Unet
+from rnr_amd import ops
+from rnr_amd.testing import ray_pivots as _ray_pivots
+
+
+class TextureMapper(nn.Module):
+    """network.py:20-99."""
+
+    def __init__(self, texture_size, texture_num_ch, mipmap_level, texture_init=None, fix_texture=False, apply_sh=False):
+        super().__init__()
+        self.register_buffer('texture_size', torch.tensor(texture_size))
+        self.register_buffer('texture_num_ch', torch.tensor(texture_num_ch))
+        self.register_buffer('mipmap_level', torch.tensor(mipmap_level))
+        self.register_buffer('apply_sh', torch.tensor(apply_sh))
+        self.textures = nn.ParameterList([])
+        self.textures_size = []
+        for lvl in range(int(mipmap_level)):
+            s = int(np.round(int(texture_size) / (2.0 ** lvl)))
+            t = torch.ones(1, s, s, int(texture_num_ch), dtype=torch.float32) * (1.0 if lvl == 0 else 0.01)
+            if texture_init is not None and lvl == 0:
+                k = texture_init.shape[-1]
+                t[..., :k] = texture_init[None]
+                t[..., k:2 * k] = texture_init[None]
+            self.textures_size.append(s)
+            self.textures.append(nn.Parameter(t))
+        self.register_buffer('tex_flatten_mipmap_init', torch.nn.functional.relu(self.flatten_mipmap(0, 6)))
+        if fix_texture:
+            for p in self.textures:
+                p.requires_grad = False
+
+    def forward(self, uv_map, sh_basis_map=None, sh_start_ch=3):
+        """uv_map [N,H,W,2], sh_basis_map [N,H,W,9] -> [N,C,H,W] (network.py:67-91)."""
+        sh = sh_basis_map.float().contiguous() if (bool(self.apply_sh) and sh_basis_map is not None) else None
+        return ops.texture_mapper([p.detach() for p in self.textures], uv_map.float().contiguous(), sh, sh_start_ch)
+
+    def flatten_mipmap(self, start_ch, end_ch):
+        """network.py:93-99 (init-time / visualisation helper)."""
+        out = None
+        for lvl, p in enumerate(self.textures):
+            t = p[..., start_ch:end_ch]
+            if lvl > 0:
+                t = torch.nn.functional.interpolate(t.permute(0, 3, 1, 2), size=(self.textures_size[0],) * 2,
+                                                    mode='bilinear').permute(0, 2, 3, 1)
+            out = t if out is None else out + t
+        return out
+
+
+class Rasterizer(nn.Module):
+    """network.py:102-216: same buffers and the same 14-tuple; one fused projection + raster + interpolation pass."""
+
+    def __init__(self, obj_fp, img_size, global_RT=None):
+        super().__init__()
+        v_attr, f_attr = nr.load_obj(obj_fp, normalization=False, use_cuda=False)
+        vertices, vn, vt = v_attr['v'], v_attr['vn'], v_attr['vt']
+        self.num_vertex, self.num_face = vertices.shape[0], f_attr['f_v_idx'].shape[0]
+        self.img_size = img_size
+        if global_RT is not None:   # network.py:126-128
+            g = global_RT.to(vertices.device).float()
+            vertices = torch.matmul(g, torch.cat((vertices, torch.ones(self.num_vertex, 1)), dim=1).t()).t()[:, :3]
+            vn = torch.nn.functional.normalize(torch.matmul(g[:3, :3], vn.t()).t(), dim=1)
+        self.register_buffer('vertices', vertices[None].contiguous())
+        self.register_buffer('faces', f_attr['f_v_idx'][None].contiguous())
+        self.register_buffer('vertices_texcoords', vt[None].contiguous())
+        self.register_buffer('faces_vt_idx', f_attr['f_vt_idx'][None].contiguous())
+        self.register_buffer('vertices_normals', vn[None].contiguous())
+        self.register_buffer('faces_vn_idx', f_attr['f_vn_idx'][None].contiguous())
+        self.mesh_span = (self.vertices[0].max(dim=0)[0] - self.vertices[0].min(dim=0)[0]).max()
+        self.textures = nn.Parameter(torch.zeros(1, self.num_face, 4, 4, 4, 3, dtype=torch.float32))  # API only (network.py:140-142)
+        renderer = nr.Renderer(image_size=img_size, camera_mode='projection', orig_size=img_size, near=0.0, far=1e5)
+        renderer.light_intensity_directional = 0.0
+        renderer.light_intensity_ambient = 1.0
+        renderer.anti_aliasing = False
+        renderer.fill_back = False
+        self.renderer = renderer
+        self._mesh = None
+
+    def _apply(self, fn, *a, **k):
+        self._mesh = None
+        return super()._apply(fn, *a, **k)
+
+    def _device_mesh(self):
+        if self._mesh is None:
+            self._mesh = ops.DeviceMesh(self.vertices[0], self.vertices_texcoords[0], self.vertices_normals[0],
+                                        self.faces[0], self.faces_vt_idx[0], self.faces_vn_idx[0], self.vertices.device)
+        return self._mesh
+
+    def forward(self, proj, pose, dist_coeffs, offset, scale):
+        if self.renderer.fill_back or self.renderer.anti_aliasing:
+            raise NotImplementedError('Rasterizer: fill_back / anti_aliasing are off on the hot path (network.py:152-153)')
+        mesh = self._device_mesh()
+        S = self.img_size
+        N = proj.shape[0]
+        R = pose[:, :3, :3].float().contiguous()
+        t = pose[:, :3, 3].float().contiguous()
+        f = lambda x: x.float().contiguous() if x is not None else None
+        v_ndc = ops.project_vertices(mesh.v, proj.float().contiguous(), R, t, S, f(dist_coeffs),
+                                     f(offset) if scale is not None else None, f(scale) if offset is not None else None)
+        gb = ops.rasterize_gbuffer(mesh, v_ndc, pose.float().contiguous(), S, self.renderer.near, self.renderer.far)
+        depth = gb['depth']
+        # network.py:170-173: vertices on the frontal surface (batch element 0 only), pixel coordinates
+        v_uvz = v_ndc.clone()
+        v_uvz[..., 0] = (v_uvz[..., 0] * 0.5 + 0.5) * S
+        v_uvz[..., 1] = (1 - (v_uvz[..., 1] * 0.5 + 0.5)) * S
+        v_depth = misc.interpolate_bilinear(depth[0, :, :, None].contiguous(), v_uvz[..., 0], v_uvz[..., 1])
+        v_front_mask = ((v_uvz[0, :, 2] - v_depth[0, :, 0]) < self.mesh_span.to(depth.device) * 5e-3)[None, :]
+        faces_v = nr.vertex_attrs_to_faces(self.vertices, self.faces)
+        faces_vt = nr.vertex_attrs_to_faces(self.vertices_texcoords, self.faces_vt_idx)
+        return (gb['uv_map'], gb['alpha'], gb['face_index_map'], gb['weight_map'][..., None], self.faces, gb['normal_map'],
+                gb['normal_map_cam'], faces_v, faces_vt, gb['position_map'], gb['position_map_cam'], depth[..., None],
+                v_uvz, v_front_mask)
+
+
+class RenderingNet(nn.Module):
+    """network.py:219-253.  forward(input [N,Cin,H,W], v_fea) -> tanh(U-Net) [N,Cout,H,W]."""
+
+    def __init__(self, nf0, in_channels, out_channels, num_down_unet=5, out_channels_gcn=512, use_gcn=True,
+                 outermost_highway_mode='concat'):
+        super().__init__()
+        self.register_buffer('nf0', torch.tensor(nf0))
+        self.register_buffer('in_channels', torch.tensor(in_channels))
+        self.register_buffer('out_channels', torch.tensor(out_channels))
+        self.register_buffer('num_down_unet', torch.tensor(num_down_unet))
+        self.register_buffer('out_channels_gcn', torch.tensor(out_channels_gcn))
+        self.net = Unet(in_channels=in_channels, out_channels=out_channels, outermost_linear=True, use_dropout=True,
+                        dropout_prob=0.1, nf0=nf0, norm=nn.BatchNorm2d, max_channels=8 * nf0, num_down=num_down_unet,
+                        out_channels_gcn=out_channels_gcn, use_gcn=use_gcn, outermost_highway_mode=outermost_highway_mode)
+        self.tanh = nn.Tanh()
+
+    def forward(self, input, v_fea):
+        return self.net.forward_fused(input, apply_tanh=True)      # tanh fused into the layout epilogue
+
+
+class Interpolater(nn.Module):
+    """network.py:318-337."""
+
+    def forward(self, data, sub_x, sub_y):
+        if data.shape[0] == 1:
+            return misc.interpolate_bilinear(data[0].contiguous(), sub_x, sub_y)
+        if data.shape[0] == sub_x.shape[0]:
+            return torch.stack([misc.interpolate_bilinear(data[i].contiguous(), sub_x[i], sub_y[i]) for i in range(data.shape[0])])
+        raise ValueError('data.shape[0] should be 1 or batch size')
+
+
+class RaySampler(nn.Module):
+    """network.py:417-472."""
+
+    def __init__(self, num_azi, num_polar, interval_polar=5, mode='reflect'):
+        super().__init__()
+        self.register_buffer('num_azi', torch.tensor(num_azi))
+        self.register_buffer('num_polar', torch.tensor(num_polar))
+        self.register_buffer('interval_polar', torch.tensor(interval_polar))
+        self.mode = mode
+        na, npol, step = int(num_azi), int(num_polar), float(interval_polar)
+        self.num_ray = na * npol + 1
+        pol = np.arange(1, npol + 1) * step * np.pi / 180.0
+        azi = np.arange(na) * 2 * np.pi / na
+        pol, azi = np.meshgrid(pol, azi)
+        self.rot_rad = np.vstack((np.zeros(na * npol), pol.flatten(), azi.flatten()))
+        Rs = np.zeros((self.num_ray, 3, 3), np.float32)
+        Rs[0] = np.eye(3)
+        for i in range(self.num_ray - 1):       # data_util.euler_to_rot with rot_x = 0 (data_util.py:175-191)
+            cy, sy = np.cos(self.rot_rad[1, i]), np.sin(self.rot_rad[1, i])
+            cz, sz = np.cos(self.rot_rad[2, i]), np.sin(self.rot_rad[2, i])
+            Rs[i + 1] = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]).dot(np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]))
+        self.register_buffer('Rs', torch.from_numpy(Rs))
+        self.register_buffer('pivots_dir', _ray_pivots(na, npol, step))
+
+    def forward(self, TBN_matrices, view_dir_map_tangent, alpha_map):
+        reflect = self.mode == 'reflect'
+        dirs, uv, dt = ops.ray_sampler(reflect, self.pivots_dir, TBN_matrices.float(), view_dir_map_tangent.float(),
+                                       alpha_map.float())
+        return dirs, uv, (dt if reflect else self.pivots_dir)
+
+
+class RayRenderer(nn.Module):
+    """network.py:475-527."""
+
+    def __init__(self, lighting_model, interpolater):
+        super().__init__()
+        self.lighting_model = lighting_model
+        self.interpolater = interpolater
+
+    def forward(self, albedo_specular, rays_uv, rays_lt, lighting_idx=None, lp=None, albedo_diffuse=None,
+                num_ray_diffuse=0, no_albedo=False, seperate_albedo=False, lp_scale_factor=1):
+        if lp is None:
+            lp = self.lighting_model(lighting_idx, is_lp=True)
+        lp_in = lp.float().contiguous()
+        out, o_s, o_d, l_s, l_d, color = ops.ray_renderer(
+            rays_uv.float().contiguous(), rays_lt.float().contiguous(), lp_in, albedo_specular.float().contiguous(),
+            albedo_diffuse.float().contiguous() if albedo_diffuse is not None else None, num_ray_diffuse, no_albedo,
+            seperate_albedo, float(lp_scale_factor))
+        return out, o_s, o_d, l_s, l_d, color, lp * lp_scale_factor
+
+
+class LightingSH(nn.Module):
+    """network.py:534-627 without pyshtools: the lmax <= 16 basis comes from the HIP SH kernel."""
+
+    def __init__(self, l_dir, lmax, num_lighting=1, num_channel=3, init_coeff=None, fix_params=False, lp_recon_h=100,
+                 lp_recon_w=200):
+        super().__init__()
+        self.num_sample, self.lmax, self.num_basis = l_dir.shape[1], lmax, (lmax + 1) ** 2
+        self.num_lighting, self.num_channel, self.fix_params = num_lighting, num_channel, fix_params
+        self.lp_recon_h, self.lp_recon_w = lp_recon_h, lp_recon_w
+        basis = torch.from_numpy(sph_harm.evaluate_sh_basis(lmax=lmax, directions=l_dir.detach().cpu().numpy().transpose()))
+        self.register_buffer('basis_val', basis.to(l_dir.dtype).to(l_dir.device))
+        self.coeff = nn.Parameter(torch.zeros((num_lighting, self.num_basis, num_channel), dtype=torch.float32))
+        if init_coeff is not None:
+            if init_coeff.dim() == 2:
+                init_coeff = init_coeff[None].repeat((num_lighting, 1, 1))
+            self.coeff.data = init_coeff
+        if fix_params:
+            self.coeff.requires_grad_(False)
+        self.register_buffer('l_samples', torch.einsum('sb,lbc->lsc', self.basis_val.cpu(), self.coeff.data.cpu()))
+        vv, uu = torch.meshgrid(torch.arange(lp_recon_h, dtype=torch.float32) / (lp_recon_h - 1),
+                                torch.arange(lp_recon_w, dtype=torch.float32) / (lp_recon_w - 1), indexing='ij')
+        dirs = render.spherical_mapping_inv(torch.stack([uu, vv]).flatten(1)).permute(1, 0).numpy()
+        self.register_buffer('basis_val_recon',
+                             torch.from_numpy(sph_harm.evaluate_sh_basis(lmax=lmax, directions=dirs)).to(l_dir.dtype))
+
+    def forward(self, lighting_idx=None, coeff=None, is_lp=None):
+        if coeff is not None:
+            return (self.reconstruct_lp(coeff) if is_lp else sph_harm.reconstruct_sh(coeff, self.basis_val))[None]
+        if lighting_idx is not None:
+            if is_lp:
+                return self.reconstruct_lp(self.coeff[lighting_idx])[None]
+            if self.fix_params:
+                return self.l_samples[lighting_idx][None]
+            return sph_harm.reconstruct_sh(self.coeff[lighting_idx][None], self.basis_val)
+        if is_lp:
+            return self.reconstruct_lp(self.coeff)[None]
+        return (self.l_samples if self.fix_params else sph_harm.reconstruct_sh(self.coeff, self.basis_val))[None]
+
+    def get_lighting_params(self, lighting_idx):
+        return self.coeff[lighting_idx]
+
+    def normalize_lighting(self, lighting_ref_idx):
+        ref = self.coeff[lighting_ref_idx].norm('fro')
+        f = ref / self.coeff.norm('fro', dim=[1, 2])
+        f[lighting_ref_idx] = 1.0
+        self.coeff *= f[:, None, None]
+
+    def reconstruct_lp(self, coeff):
+        lp = sph_harm.reconstruct_sh(coeff.detach(), self.basis_val_recon)
+        return lp.reshape(lp.shape[:-2] + (int(self.lp_recon_h), int(self.lp_recon_w), lp.shape[-1]))
+
+
+def _out_of_scope(name, why):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError('network.%s is outside the MI355X hot-path build: %s' % (name, why))
+    _Stub.__name__ = name
+    return _Stub
+
+
+DenseDeepGCN = _out_of_scope('DenseDeepGCN', 'train-time only; inference loads its cached output v_feature, which is dead at the output')
+InterpolaterVertexAttr = _out_of_scope('InterpolaterVertexAttr', 'unused at inference')
+Mesh = _out_of_scope('Mesh', 'only feeds the GCN')
+RaysLTChromLoss = _out_of_scope('RaysLTChromLoss', 'training loss')
+LightingLP = _out_of_scope('LightingLP', 'needs cv2 INTER_AREA resize of 1600x3200 probes; SURVEY §8(f) rank 2')

@@ -74,6 +74,15 @@ SIGNATURES = {
     'rnr_sh_fit': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_interpolate_bilinear': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p]),
+    'rnr_view_dir_map': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_tbn_map': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_ray_sampler': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                ctypes.c_long, c_void_p]),
+    'rnr_texture_mapper': (c_int, [c_void_p, c_void_p, P(c_void_p), P(c_int), c_int, c_int, c_int, c_void_p, c_int,
+                                   c_int, c_int, c_void_p]),
+    'rnr_ray_renderer': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

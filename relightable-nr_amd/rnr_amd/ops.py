@@ -244,3 +244,101 @@ def nhwc_to_nchw(x, c, bias=None, apply_tanh=False):
     out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
     check(L.rnr_nhwc_to_nchw(_ptr(x), _ptr(out), _ptr(bias), int(apply_tanh), n, c, h, w, c_pad, _stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# stand-alone operators behind the drop-in Python API
+# ---------------------------------------------------------------------------------------------------
+def view_dir_map(img_hw, proj_inv, R_inv):
+    """camera.get_view_dir_map -> (world [N,H,W,3], cam [N,H,W,3])."""
+    L = _lib.load()
+    _chk(proj_inv, 'proj_inv'); _chk(R_inv, 'R_inv')
+    N, H, W = proj_inv.shape[0], int(img_hw[0]), int(img_hw[1])
+    world = torch.empty(N, H, W, 3, dtype=torch.float32, device=proj_inv.device)
+    cam = torch.empty_like(world)
+    check(L.rnr_view_dir_map(_ptr(proj_inv), _ptr(R_inv), _ptr(world), _ptr(cam), N, H, W, _stream()))
+    return world, cam
+
+
+def face_tangents(faces_v, faces_vt):
+    """Per-face unit tangents from gathered per-face positions [nf,3,3] and texcoords [nf,3,2] (render.py:135-150)."""
+    L = _lib.load()
+    nf = faces_v.shape[0]
+    dev = faces_v.device
+    v = faces_v.reshape(nf * 3, 3).float().contiguous()
+    vt = faces_vt.reshape(nf * 3, 2).float().contiguous()
+    idx = torch.arange(nf * 3, dtype=torch.int32, device=dev).reshape(nf, 3).contiguous()
+    mesh = RnrMesh(v.data_ptr(), vt.data_ptr(), None, idx.data_ptr(), idx.data_ptr(), None, nf * 3, nf * 3, 0, nf)
+    out = torch.empty(nf, 3, dtype=torch.float32, device=dev)
+    check(L.rnr_face_tangents(ctypes.byref(mesh), _ptr(out), _stream()))
+    return out
+
+
+def tbn_map(normal_map, face_index_map, tangents):
+    """render.get_TBN_map body given unit per-face tangents -> [N,H,W,3,3]."""
+    L = _lib.load()
+    _chk(normal_map, 'normal_map'); _chk(face_index_map, 'face_index_map', torch.int32); _chk(tangents, 'tangents')
+    N, H, W = face_index_map.shape
+    out = torch.empty(N, H, W, 3, 3, dtype=torch.float32, device=normal_map.device)
+    check(L.rnr_tbn_map(_ptr(normal_map), _ptr(face_index_map), _ptr(tangents), tangents.shape[0], _ptr(out), N, H, W,
+                        _stream()))
+    return out
+
+
+def ray_sampler(reflect, pivots, tbn, view_tangent, alpha):
+    """network.RaySampler.forward.  tbn [...,3,3], view_tangent [...,3], alpha [...,1] -> dirs [...,3,R], uv [...,2,R],
+    dirs_tangent [...,3,R] (reflect) or the pivots (diffuse)."""
+    L = _lib.load()
+    lead = tbn.shape[:-2]
+    npix = 1
+    for d in lead:
+        npix *= int(d)
+    R = int(pivots.shape[1])
+    dev = tbn.device
+    tb = _chk(tbn.reshape(npix, 3, 3).contiguous(), 'tbn')
+    al = _chk(alpha.reshape(npix).contiguous(), 'alpha')
+    vt = _chk(view_tangent.reshape(npix, 3).contiguous(), 'view_tangent') if reflect else None
+    piv = pivots.detach().cpu().contiguous().float()
+    dirs = torch.empty(lead + (3, R), dtype=torch.float32, device=dev)
+    uv = torch.empty(lead + (2, R), dtype=torch.float32, device=dev)
+    dt = torch.empty(lead + (3, R), dtype=torch.float32, device=dev) if reflect else None
+    check(L.rnr_ray_sampler(int(bool(reflect)), piv.data_ptr(), R, _ptr(tb), _ptr(vt), _ptr(al), _ptr(dirs), _ptr(uv),
+                            _ptr(dt), npix, _stream()))
+    return dirs, uv, dt
+
+
+def texture_mapper(textures, uv_map, sh_basis_map=None, sh_start_ch=3):
+    """network.TextureMapper.forward for any channel count -> [N,C,H,W]."""
+    L = _lib.load()
+    _chk(uv_map, 'uv_map')
+    N, H, W = uv_map.shape[:3]
+    tex = [_chk(t.reshape(t.shape[-3], t.shape[-2], t.shape[-1]).contiguous(), 'texture') for t in textures]
+    C = tex[0].shape[-1]
+    nl = len(tex)
+    ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in tex])
+    sizes = (ctypes.c_int * nl)(*[int(t.shape[0]) for t in tex])
+    out = torch.empty(N, C, H, W, dtype=torch.float32, device=uv_map.device)
+    if sh_basis_map is not None:
+        _chk(sh_basis_map, 'sh_basis_map')
+    check(L.rnr_texture_mapper(_ptr(uv_map), _ptr(sh_basis_map), ptrs, sizes, nl, C, int(sh_start_ch), _ptr(out), N, H, W,
+                               _stream()))
+    return out
+
+
+def ray_renderer(rays_uv, rays_lt, lp, albedo_specular, albedo_diffuse=None, num_ray_diffuse=0, no_albedo=False,
+                 seperate_albedo=False, lp_scale_factor=1.0):
+    """network.RayRenderer.forward on API-shaped tensors -> (out, out_spec, out_diff, ltt_spec, ltt_diff, rays_color)."""
+    L = _lib.load()
+    _chk(rays_uv, 'rays_uv'); _chk(rays_lt, 'rays_lt'); _chk(lp, 'lp'); _chk(albedo_specular, 'albedo_specular')
+    N, R, C, H, W = rays_lt.shape
+    if albedo_diffuse is not None:
+        _chk(albedo_diffuse, 'albedo_diffuse')
+    dev = rays_lt.device
+    mk = lambda: torch.empty(N, C, H, W, dtype=torch.float32, device=dev)
+    out, o_s, o_d, l_s, l_d = mk(), mk(), mk(), mk(), mk()
+    color = torch.empty(N, R, C, H, W, dtype=torch.float32, device=dev)
+    check(L.rnr_ray_renderer(_ptr(rays_uv), _ptr(rays_lt), _ptr(lp), lp.shape[0], lp.shape[1], lp.shape[2],
+                             _ptr(albedo_specular), _ptr(albedo_diffuse), C, R, int(num_ray_diffuse), int(bool(no_albedo)),
+                             int(bool(seperate_albedo)), float(lp_scale_factor), _ptr(out), _ptr(o_s), _ptr(o_d), _ptr(l_s),
+                             _ptr(l_d), _ptr(color), N, H, W, _stream()))
+    return out, o_s, o_d, l_s, l_d, color

@@ -33,7 +33,9 @@ class _Act:
 
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
-                 prefix='net.', in_c_pad=None):
+                 prefix='net.', in_c_pad=None, bn_mode='batch'):
+        """bn_mode 'batch': BatchNorm2d in train mode (per-view batch statistics, what test_rnr.py:229-233 forces);
+        'running': eval-mode BatchNorm from the running_mean / running_var buffers of the state-dict."""
         self.L = _lib.load()
         self.dev = device
         self.N = int(max_views)
@@ -65,7 +67,13 @@ class UNetPlan:
             out = _Act(c_out, desc.c_out_pad, oh, ow, act)
             out.data = torch.empty(self.N, oh, ow, desc.c_out_pad, dtype=torch.float32, device=device)
             step = {'desc': desc, 'packed': packed, 'srcs': srcs, 'out': out, 'in_hw': (s0.h, s0.w), 'bn': None}
-            if bn_key is not None and has(bn_key + '.weight'):
+            if bn_key is not None and has(bn_key + '.weight') and bn_mode == 'running':
+                gamma, beta = g(bn_key + '.weight'), g(bn_key + '.bias')
+                sc = gamma / torch.sqrt(g(bn_key + '.running_var') + 1e-5)
+                sh = beta - g(bn_key + '.running_mean') * sc
+                pad = lambda t: torch.cat([t, torch.zeros(desc.c_out_pad - c_out, device=device)])[None].repeat(self.N, 1)
+                out.scale, out.shift = pad(sc).contiguous(), pad(sh).contiguous()
+            elif bn_key is not None and has(bn_key + '.weight'):
                 gamma, beta = g(bn_key + '.weight'), g(bn_key + '.bias')
                 out.scale = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
                 out.shift = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)

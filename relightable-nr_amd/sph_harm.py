@@ -1,0 +1,55 @@
+"""Drop-in `sph_harm` (reference: sph_harm.py) without pyshtools: the basis is evaluated by the HIP kernel
+(real, orthonormal, no Condon-Shortley phase, columns l = 0..lmax, m = -l..l)."""
+import numpy as np
+import torch
+
+from rnr_amd import ops
+
+
+def cart2sph(x, y, z):
+    """sph_harm.py:6-19."""
+    if type(x) is torch.Tensor:
+        return torch.atan2(y, x), torch.atan2(z, torch.sqrt(x ** 2 + y ** 2)), torch.sqrt(x ** 2 + y ** 2 + z ** 2)
+    return np.arctan2(y, x), np.arctan2(z, np.sqrt(x ** 2 + y ** 2)), np.sqrt(x ** 2 + y ** 2 + z ** 2)
+
+
+def sph2cart(azimuth, elevation, r):
+    """sph_harm.py:22-38."""
+    m = torch if type(azimuth) is torch.Tensor else np
+    ce = m.cos(elevation)
+    return r * ce * m.cos(azimuth), r * ce * m.sin(azimuth), r * m.sin(elevation)
+
+
+def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device='cuda'):
+    """sph_harm.py:41-71.  directions [n,3] (numpy or tensor) or azi/pol in degrees -> np.ndarray [n,(lmax+1)^2]
+    (float64 container like the reference; values carry float32 precision, which is what every caller casts to)."""
+    if directions is None:
+        a, p = np.deg2rad(np.asarray(azi, np.float64)), np.deg2rad(np.asarray(pol, np.float64))
+        directions = np.stack([np.sin(p) * np.cos(a), np.sin(p) * np.sin(a), np.cos(p)], -1)
+    d = torch.as_tensor(np.asarray(directions, np.float32)).contiguous().to(device)
+    return ops.sh_basis(d, int(lmax)).cpu().numpy().astype(np.float64)
+
+
+def fit_sh_coeff(samples, sh_basis_val):
+    """sph_harm.py:74-88.  samples [ns,C] or [L,ns,C], basis [ns,nb] -> [nb,C] or [L,nb,C]."""
+    if not torch.is_tensor(samples):
+        w = 4.0 * np.pi / samples.shape[-2]
+        if samples.ndim == 2:
+            return (samples[:, None, :] * sh_basis_val[:, :, None]).sum(-3) * w
+        return (samples[:, :, None, :] * sh_basis_val[None, :, :, None]).sum(-3) * w
+    b = sh_basis_val.float().contiguous()
+    if samples.dim() == 2:
+        return ops.sh_fit(samples.float().contiguous(), b)
+    return torch.stack([ops.sh_fit(s.float().contiguous(), b) for s in samples])
+
+
+def reconstruct_sh(sh_coeff, sh_basis_val):
+    """sph_harm.py:91-102.  coeff [nb,C] or [L,nb,C], basis [ns,nb] -> [ns,C] or [L,ns,C]."""
+    if not torch.is_tensor(sh_coeff):
+        if sh_coeff.ndim == 2:
+            return (sh_basis_val[..., None] * sh_coeff[None, :]).sum(-2)
+        return (sh_basis_val[None, :, :, None] * sh_coeff[:, None, :, :]).sum(-2)
+    b = sh_basis_val.float().contiguous()
+    if sh_coeff.dim() == 2:
+        return ops.sh_reconstruct(b, sh_coeff.float().contiguous())
+    return torch.stack([ops.sh_reconstruct(b, c.float().contiguous()) for c in sh_coeff])

@@ -1,0 +1,161 @@
+"""-m gpu: the reference's per-view loop (test_rnr.py:265-377) written against the DROP-IN modules
+(`network`, `render`, `camera`, `sph_harm`, `neural_renderer`), compared with the golden vectors the reference's own
+modules produced.  This is the "a user switches the import path and nothing else" check."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def test_rnr_view_loop_with_dropin_modules(golden, tmp_path):
+    import camera
+    import network
+    import render
+    import sph_harm
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    gm, gf = golden('rasterizer_module64'), golden('frame64')
+    obj = str(tmp_path / 'sphere.obj')
+    scene.write_obj(obj, {k: gm['mesh_' + k] for k in ['v', 'vt', 'vn', 'f_v_idx', 'f_vt_idx', 'f_vn_idx']})
+    S = 64
+    rasterizer = network.Rasterizer(obj_fp=obj, img_size=S, global_RT=T(gm['global_RT'])).to(DEV)
+    assert torch.allclose(rasterizer.vertices.cpu(), T(gm['buf_vertices']), atol=1e-6)
+    texture_mapper = network.TextureMapper(32, 16, 4, apply_sh=True)
+    tsd = texture_mapper.state_dict()
+    for i in range(4):
+        tsd['textures.%d' % i] = T(gf['tex%d' % i])
+    texture_mapper.load_state_dict(tsd, strict=True)
+    ray_sampler = network.RaySampler(6, 2, 5)
+    ray_sampler_diffuse = network.RaySampler(6, 2, 10, mode='diffuse')
+    nr_total = ray_sampler.num_ray + ray_sampler_diffuse.num_ray
+    render_net = network.RenderingNet(nf0=4, in_channels=nr_total * 3 + 6 + 16, out_channels=3 * nr_total, num_down_unet=5,
+                                      out_channels_gcn=16)
+    sd = render_net.state_dict()
+    for k in gf.files:
+        if k.startswith('sd:'):
+            sd[k[3:]] = T(gf[k])
+    render_net.load_state_dict(sd, strict=True)
+    ray_renderer = network.RayRenderer(None, network.Interpolater())
+    for m in (texture_mapper, ray_sampler, ray_sampler_diffuse, render_net, ray_renderer):
+        m.to(DEV).eval()
+    for m in render_net.modules():        # test_rnr.py:229-233
+        if type(m) == torch.nn.BatchNorm2d:
+            m.train()
+    v_feature = torch.zeros(1, 16, device=DEV)
+    lp = T(gf['lp']).to(DEV)
+    names = ['uv_map', 'alpha', 'face_index_map', 'weight_map', 'faces_v_idx', 'normal_map', 'normal_map_cam', 'faces_v',
+             'faces_vt', 'position_map', 'position_map_cam', 'depth', 'v_uvz', 'v_front_mask']
+    with torch.no_grad():
+        for i in range(2):
+            proj, pose = T(gm['proj'][i:i + 1]).to(DEV), T(gm['pose'][i:i + 1]).to(DEV)
+            proj_inv, R_inv = T(gm['proj_inv'][i:i + 1]).to(DEV), T(gm['R_inv'][i:i + 1]).to(DEV)
+            tup = rasterizer(proj=proj, pose=pose, dist_coeffs=None, offset=None, scale=None)
+            assert len(tup) == 14
+            mism = (tup[2].cpu().numpy() != gm['view%d_face_index_map' % i])
+            assert mism.mean() < 2e-3
+            for n, x in zip(names, tup):
+                ref = gm['view%d_%s' % (i, n)]
+                assert tuple(x.shape) == tuple(ref.shape), (n, x.shape, ref.shape)
+            assert torch.equal(tup[13].cpu(), T(gm['view%d_v_front_mask' % i]))
+            assert np.abs(tup[12].cpu().numpy() - gm['view%d_v_uvz' % i]).max() < 1e-3
+            uv_map, alpha_map, face_index_map, _, _, normal_map, _, faces_v, faces_vt = tup[:9]
+            TBN_map = render.get_TBN_map(normal_map, face_index_map, faces_v=faces_v[0], faces_texcoord=faces_vt[0])
+            view_dir_map, _ = camera.get_view_dir_map(uv_map.shape[1:3], proj_inv, R_inv)
+            vt = torch.matmul(TBN_map.reshape((-1, 3, 3)).transpose(-2, -1), view_dir_map.reshape((-1, 3, 1)))[..., 0]
+            view_dir_map_tangent = torch.nn.functional.normalize(vt.reshape(view_dir_map.shape), dim=-1)
+            sh_np = sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape((-1, 3)).cpu().numpy())
+            sh_basis_map = torch.from_numpy(sh_np.reshape((1, S, S, -1)).astype(np.float32)).to(DEV)
+            assert np.abs(sh_basis_map.cpu().numpy()[~mism] - gf['sh_basis_map'][i:i + 1][~mism]).max() < 2e-6
+            neural_img = texture_mapper(uv_map, sh_basis_map, sh_start_ch=6)
+            rays_dir, rays_uv, _ = ray_sampler(TBN_map, view_dir_map_tangent, alpha_map[..., None])
+            rays_d_dir, rays_d_uv, _ = ray_sampler_diffuse(TBN_map, view_dir_map_tangent, alpha_map[..., None])
+            rays_dir = torch.cat((rays_dir, rays_d_dir), dim=-1)
+            rays_uv = torch.cat((rays_uv, rays_d_uv), dim=-1)
+            net_in = torch.cat((rays_dir.permute((0, -1, -2, 1, 2)).reshape((1, -1, S, S)), normal_map.permute((0, 3, 1, 2)),
+                                view_dir_map.permute((0, 3, 1, 2)), neural_img), dim=1)
+            ok = torch.from_numpy(~mism)[:, None].expand_as(net_in.cpu())
+            assert (net_in.cpu() - T(gf['net_in'][i:i + 1]).float())[ok].abs().max() < 2e-3      # golden stored as fp16
+            rays_lt = render_net(net_in, v_feature).reshape((1, nr_total, -1, S, S))
+            rays_lt = (rays_lt * 0.5 + 0.5) * 2.0
+            out = ray_renderer(neural_img[:, 3:6], rays_uv, rays_lt, lp=lp, albedo_diffuse=neural_img[:, :3],
+                               num_ray_diffuse=ray_sampler_diffuse.num_ray, seperate_albedo=True)
+            assert len(out) == 7
+            p = orc.psnr(out[0].cpu(), T(gf['image'][i:i + 1]))
+            assert p > 55.0, p
+
+
+def test_dropin_ops_vs_golden(golden):
+    """TextureMapper (any C), RaySampler, RayRenderer, get_TBN_map, get_view_dir_map one by one."""
+    import camera
+    import network
+    import render
+    g = golden('texture_mapper')
+    tm = network.TextureMapper(32, 16, 4, apply_sh=True)
+    sd = tm.state_dict()
+    for i in range(4):
+        sd['textures.%d' % i] = T(g['tex%d' % i])
+    tm.load_state_dict(sd, strict=True)
+    tm.to(DEV)
+    uv, sh = T(g['uv']).to(DEV), T(g['sh']).to(DEV)
+    assert torch.allclose(tm(uv, sh, sh_start_ch=6).cpu(), T(g['out_sh6']), atol=2e-6)
+    assert torch.allclose(tm(uv, sh).cpu(), T(g['out_sh3']), atol=2e-6)
+    assert torch.allclose(tm(uv, None).cpu(), T(g['out_nosh']), atol=2e-6)
+    g = golden('shading_geometry64')
+    tbn = render.get_TBN_map(T(g['normal_map']).to(DEV), T(g['face_index_map']).to(DEV), faces_v=T(g['faces_v'])[0].to(DEV),
+                             faces_texcoord=T(g['faces_vt'])[0].to(DEV), check_nan=True)
+    assert torch.allclose(tbn.cpu(), T(g['tbn']), atol=2e-6)
+    vd, vdc = camera.get_view_dir_map((64, 64), T(g['proj_inv']).to(DEV), T(g['R_inv']).to(DEV))
+    assert torch.allclose(vd.cpu(), T(g['view_dir']), atol=2e-6) and torch.allclose(vdc.cpu(), T(g['view_dir_cam']), atol=2e-6)
+    rs, rd = network.RaySampler(6, 2, 5).to(DEV), network.RaySampler(6, 2, 10, mode='diffuse').to(DEV)
+    assert torch.allclose(rs.Rs.cpu(), T(g['Rs_spec']), atol=1e-7) and torch.allclose(rs.pivots_dir.cpu(), T(g['pivots_spec']), atol=1e-7)
+    alpha = T(g['alpha'])[..., None].to(DEV)
+    d, uvr, dt = rs(T(g['tbn']).to(DEV), T(g['view_tangent']).to(DEV), alpha)
+    assert torch.allclose(d.cpu(), T(g['rays_dir_spec']), atol=2e-5)
+    assert torch.allclose(uvr.cpu(), T(g['rays_uv_spec']), atol=2e-5)
+    assert torch.allclose(dt.cpu(), T(g['rays_dir_tangent_spec']), atol=2e-5)
+    d, uvr, _ = rd(T(g['tbn']).to(DEV), T(g['view_tangent']).to(DEV), alpha)
+    assert torch.allclose(d.cpu(), T(g['rays_dir_diff']), atol=2e-5) and torch.allclose(uvr.cpu(), T(g['rays_uv_diff']), atol=2e-5)
+    g = golden('ray_renderer')
+    rr = network.RayRenderer(None, network.Interpolater())
+    out = rr(T(g['albedo_specular']).to(DEV), T(g['rays_uv']).to(DEV), T(g['rays_lt']).to(DEV), lp=T(g['lp']).to(DEV),
+             albedo_diffuse=T(g['albedo_diffuse']).to(DEV), num_ray_diffuse=13, seperate_albedo=True)
+    for a, k in zip(out, ['out', 'out_specular', 'out_diffuse', 'ltt_specular', 'ltt_diffuse', 'rays_color']):
+        assert torch.allclose(a.cpu(), T(g[k]), atol=5e-6), k
+    out = rr(T(g['albedo_specular']).to(DEV), T(g['rays_uv']).to(DEV), T(g['rays_lt']).to(DEV), lp=T(g['lp']).to(DEV))
+    assert torch.allclose(out[0].cpu(), T(g['out_nodiffuse']), atol=5e-6)
+
+
+def test_lighting_sh_module():
+    import network
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    l_dir = T(scene.sphere_samples(4096)).t().contiguous()
+    coeff = T(scene.synthetic_sh_coeff(2, 10, 1))
+    lm = network.LightingSH(l_dir, lmax=10, num_lighting=2, init_coeff=coeff, fix_params=True).to(DEV)
+    assert lm.basis_val.shape == (4096, 121) and lm.basis_val_recon.shape == (20000, 121)
+    lp = lm(lighting_idx=1, is_lp=True)
+    assert lp.shape == (1, 100, 200, 3)
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    ref = orc.reconstruct_lp(coeff[1], basis)
+    assert torch.allclose(lp[0].cpu(), ref, atol=2e-5)
+
+
+def test_neural_renderer_api_on_gpu(golden):
+    """nr.Renderer / nr.rasterize_rgbad through the drop-in package vs the kernel golden (flip included)."""
+    import neural_renderer as nr
+    g = golden('raster_sphere128')
+    faces = T(g['faces']).to(DEV)
+    out = nr.rasterize_rgbad(faces, None, 128, anti_aliasing=False, near=0.0, far=1e5, return_rgb=False)
+    assert np.array_equal(out['face_index_map'].cpu().numpy(), g['face_index_map'][:, ::-1])
+    assert np.array_equal(out['depth'].cpu().numpy(), g['depth_map'][:, ::-1])
+    assert np.array_equal(out['alpha'].cpu().numpy(), (g['face_index_map'][:, ::-1] >= 0).astype(np.float32))
+    tex = torch.zeros(2, faces.shape[1], 4, 4, 4, 3, device=DEV)
+    out = nr.rasterize_rgbad(faces, tex, 64, anti_aliasing=True, near=0.0, far=1e5, eps=1e-3)
+    assert out['rgb'].shape == (2, 3, 64, 64) and out['alpha'].shape == (2, 64, 64)
+    assert float(out['rgb'].abs().max()) == 0.0
