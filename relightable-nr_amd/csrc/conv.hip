@@ -41,7 +41,24 @@ struct ConvParams {
     int chunks0, chunks_per_tap, kt_total;
     int splitk;
     long slab_stride;   // floats between split-K slabs
+    int mtiles, ntiles, zdim;   // logical grid; the launch is 1-D and remapped per XCD (see tile_coords)
 };
+
+// XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only), and each XCD has a
+// private 4 MiB L2.  Give every XCD a contiguous run of logical tiles so that vertically adjacent pixel tiles (which
+// share their 3x3 halo rows) and the column tiles of one pixel tile (which share the whole A operand) meet in the same
+// L2.  Bijective for any tile count (cdna_hip_programming.md, "XCD swizzle must be bijective").
+__device__ __forceinline__ void tile_coords(const ConvParams& P, int& mt, int& nt, int& z) {
+    const int total = P.mtiles * P.ntiles * P.zdim;
+    const int b = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    nt = id % P.ntiles;
+    const int t = id / P.ntiles;
+    mt = t % P.mtiles;
+    z = t / P.mtiles;
+}
 
 __device__ __forceinline__ int reflect1(int i, int n) {   // ReflectionPad2d(1)
     i = i < 0 ? -i : i;
@@ -73,9 +90,11 @@ conv_mfma_kernel(const ConvParams P) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int wm0 = wave_m * WM * 32, wn0 = wave_n * WN * 32;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int par = (KIND == 2) ? (int)(blockIdx.z & 3) : 0;
-    const int split = (KIND == 2) ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    int mt_, nt_, z_;
+    tile_coords(P, mt_, nt_, z_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int par = (KIND == 2) ? (z_ & 3) : 0;
+    const int split = (KIND == 2) ? (z_ >> 2) : z_;
     const int py = par >> 1, px = par & 1;
     const int hw_rows = P.Ho * P.Wo;
 
@@ -439,7 +458,7 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
 
 template <int KIND>
 static void launch_kind(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
-    const dim3 grid(pl.mtiles, pl.ntiles, pl.splitk * pl.par);
+    const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
     if (pl.cfg == 0) hipLaunchKernelGGL((conv_mfma_kernel<KIND, 4, 1, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
     else if (pl.cfg == 1) hipLaunchKernelGGL((conv_mfma_kernel<KIND, 4, 1, 2, 3>), grid, dim3(CTHREADS), 0, st, P);
     else hipLaunchKernelGGL((conv_mfma_kernel<KIND, 2, 2, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
@@ -513,6 +532,7 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
     P.c_out = d->c_out; P.c_out_pad = d->c_out_pad;
     P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
     P.splitk = pl.splitk;
+    P.mtiles = pl.mtiles; P.ntiles = pl.ntiles; P.zdim = pl.splitk * pl.par;
     const size_t out_floats = (size_t)num_views * pl.OH * pl.OW * d->c_out_pad;
     if (stats) RNR_HIP(hipMemsetAsync(stats, 0, (size_t)num_views * d->c_out_pad * 2 * sizeof(double), st));
     if (pl.splitk > 1) {
