@@ -331,6 +331,233 @@ conv_mfma_kernel(const ConvParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolutions on maps at least 32 pixels wide: LDS halo reuse.
+//
+// A workgroup owns a 32 x TH output tile (TH = 8 or 4).  For every 16-channel chunk it stages the (TH+2) x 34 input
+// halo ONCE in LDS (reflection padding, the producer's BatchNorm/bias/activation and the skip concat applied on the
+// way in) and runs all nine taps from it: for tap (ky,kx) the MFMA A operand of output row y, lane x is the halo
+// element (y+ky, x+kx) — 32 consecutive LDS dwords, conflict-free.  Compared with the tap-by-tap gather of
+// conv_mfma_kernel this cuts the L2->LDS traffic, the global-load / ds_write instruction count and the prologue math
+// of the A operand by 256*9/340 = 6.8x (TH = 8); the MFMA work is identical.
+// Pipeline step = one (chunk, tap): weights of the next step and one float4 of the next chunk's halo are fetched to
+// registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
+// ------------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(CTHREADS)
+conv3x3_halo_kernel(const ConvParams P) {
+    constexpr int TW = 32, TH = WAVES_M * WM;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int LDA = HP;                               // 340 / 204: 4*LDA % 32 == 16 -> <= 2-way ds_write conflicts
+    constexpr int ASLOTS = HP * 4;                        // float4 slots of one halo chunk
+    constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
+    constexpr int LDB = BN + 4;
+    constexpr int BQ = BK * BN / 4;
+    constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
+    static_assert(APT <= 9, "halo loads are spread over the nine tap steps");
+    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int wn0 = wave_n * WN * 32;
+    int mt_, nt_, z_;
+    tile_coords(P, mt_, nt_, z_);
+    const int split = z_;
+    const int n0 = nt_ * BN;
+    const int tiles_x = P.W / TW, tiles_y = P.H / TH;
+    const int n = mt_ / (tiles_x * tiles_y);
+    const int trem = mt_ - n * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+
+    // halo slots of this thread: fixed source pixels for the whole K loop
+    const int q = tid & 3;
+    int spix[APT], sdst[APT];
+#pragma unroll
+    for (int j = 0; j < APT; j++) {
+        const int s = tid + CTHREADS * j;
+        const int hp = s >> 2;
+        spix[j] = -1;
+        sdst[j] = (4 * q) * LDA + hp;
+        if (s < ASLOTS) {
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int iy = reflect1(y0 - 1 + hy, P.H), ix = reflect1(x0 - 1 + hx, P.W);
+            spix[j] = (n * P.H + iy) * P.W + ix;
+        }
+    }
+
+    const int nchunks = P.chunks_per_tap;
+    const int per_split = (nchunks + P.splitk - 1) / P.splitk;
+    const int c_begin = split * per_split;
+    const int c_end = min(nchunks, c_begin + per_split);
+
+    struct ChunkSrc { const float* data; int C, cc, act; float4 sc, sh; };
+    auto chunk_src = [&](int c) {
+        ChunkSrc cs;
+        const int s = c < P.chunks0 ? 0 : 1;
+        cs.cc = (c - (s ? P.chunks0 : 0)) * BK + 4 * q;
+        cs.C = P.src_c[s];
+        cs.data = P.src_data[s];
+        cs.act = P.src_act[s];
+        cs.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        cs.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.src_scale[s]) cs.sc = *reinterpret_cast<const float4*>(P.src_scale[s] + (size_t)n * cs.C + cs.cc);
+        if (P.src_shift[s]) cs.sh = *reinterpret_cast<const float4*>(P.src_shift[s] + (size_t)n * cs.C + cs.cc);
+        return cs;
+    };
+    auto load_a = [&](const ChunkSrc& cs, int j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (spix[j] >= 0) v = *reinterpret_cast<const float4*>(cs.data + (size_t)spix[j] * cs.C + cs.cc);
+        return v;
+    };
+    auto store_a = [&](const ChunkSrc& cs, float4 v, int j, int buf) {
+        if (spix[j] >= 0) {
+            float* a = &As[buf][sdst[j]];
+            a[0 * LDA] = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
+            a[1 * LDA] = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
+            a[2 * LDA] = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
+            a[3 * LDA] = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
+        }
+    };
+    float4 breg[BPT];
+    auto load_b = [&](int c, int t) {
+        const size_t krow0 = ((size_t)t * nchunks + c) * BK;
+#pragma unroll
+        for (int b = 0; b < BPT; b++) {
+            const int idx = tid + CTHREADS * b;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < BQ) {
+                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
+                const int col = n0 + 4 * c4;
+                if (col < P.c_out_pad) w = *reinterpret_cast<const float4*>(P.weight + (krow0 + kr) * P.c_out_pad + col);
+            }
+            breg[b] = w;
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int b = 0; b < BPT; b++) {
+            const int idx = tid + CTHREADS * b;
+            if (idx < BQ) {
+                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[buf][kr * LDB + 4 * c4]) = breg[b];
+            }
+        }
+    };
+
+    floatx16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+
+    if (c_begin < c_end) {
+        const ChunkSrc cs = chunk_src(c_begin);
+#pragma unroll
+        for (int j = 0; j < APT; j++) store_a(cs, load_a(cs, j), j, 0);
+        load_b(c_begin, 0);
+        store_b(0);
+    }
+    __syncthreads();
+    int step = 0;
+    for (int c = c_begin; c < c_end; c++) {
+        const int abuf = (c - c_begin) & 1;
+        const bool next_chunk = c + 1 < c_end;
+        ChunkSrc csn;
+        if (next_chunk) csn = chunk_src(c + 1);
+#pragma unroll
+        for (int t = 0; t < 9; t++, step++) {
+            const bool more = next_chunk || t < 8;
+            if (more) {
+                if (t < 8) load_b(c, t + 1); else load_b(c + 1, 0);
+            }
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (next_chunk && t < APT) av = load_a(csn, t);
+            const int ky = t / 3, kx = t % 3;
+            const float* a_s = &As[abuf][(wave_m * WM + ky) * HWD + kx + l31];
+            const float* b_s = &Bs[step & 1][wn0 + l31];
+#pragma unroll
+            for (int s = 0; s < BK / 2; s++) {
+                const int k = 2 * s + h;
+                float a[WM], b[WN];
+#pragma unroll
+                for (int i = 0; i < WM; i++) a[i] = a_s[k * LDA + i * HWD];
+#pragma unroll
+                for (int j = 0; j < WN; j++) b[j] = b_s[k * LDB + 32 * j];
+#pragma unroll
+                for (int i = 0; i < WM; i++)
+#pragma unroll
+                    for (int j = 0; j < WN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (next_chunk && t < APT) store_a(csn, av, t, abuf ^ 1);
+            if (more) store_b((step + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    float* out = P.out + (size_t)split * P.slab_stride;
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+        const int y = y0 + wave_m * WM + i;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int x = x0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const size_t off = (((size_t)n * P.H + y) * P.W + x) * P.c_out_pad;
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                const int col = n0 + wn0 + 32 * j + l31;
+                if (col < P.c_out_pad) out[off + col] = acc[i][j][g];
+            }
+        }
+    }
+    if (P.stats && P.splitk == 1) {
+        float* red = &As[0][0];   // [WAVES_M][BN][2]
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const float v = acc[i][j][g];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                const int col = wn0 + 32 * j + l31;
+                red[(wave_m * BN + col) * 2 + 0] = s1;
+                red[(wave_m * BN + col) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int col = n0 + tid;
+            if (col < P.c_out) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < WAVES_M; w++) {
+                    s1 += (double)red[(w * BN + tid) * 2 + 0];
+                    s2 += (double)red[(w * BN + tid) * 2 + 1];
+                }
+                double* st = P.stats + ((size_t)n * P.c_out_pad + col) * 2;
+                atomicAdd(st + 0, s1);
+                atomicAdd(st + 1, s2);
+            }
+        }
+    }
+}
+
 // out[m,c] = sum_s slab[s][m,c]; statistics per view.  grid (rows/64, c_out_pad/64), 256 threads.
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk, float* __restrict__ out,
@@ -423,6 +650,7 @@ pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restri
 }
 
 struct ConvPlan {
+    int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
     int cfg;        // 0: 256x64, 1: 256x96, 2: 128x128
     int bm, bn, mtiles, ntiles, par, splitk;
     int Ho, Wo, OH, OW, M;
@@ -443,17 +671,29 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     else { p->cfg = 2; p->bm = 128; p->bn = 128; }
     p->mtiles = (p->M + p->bm - 1) / p->bm;
     p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+    const int th = p->bm / 32;       // halo kernel: 32 x th pixel tiles (all tile pixels must be inside the map)
+    p->halo = (d->kind == RNR_CONV3x3_REFLECT && W % 32 == 0 && H % th == 0) ? 1 : 0;
+    if (p->halo) p->mtiles = N * (H / th) * (W / 32);
     const long tiles = (long)p->mtiles * p->ntiles * p->par;
     int sk = 1;
     if (tiles < 256) {
         sk = (int)((512 + tiles - 1) / tiles);
-        const int max_sk = p->kt_total / 4 > 0 ? p->kt_total / 4 : 1;
+        // split granularity: K-chunks x taps for the gather kernel, K-chunks (all nine taps) for the halo kernel
+        const int units = p->halo ? p->chunks_per_tap : p->kt_total / 4;
+        const int max_sk = units > 0 ? units : 1;
         if (sk > max_sk) sk = max_sk;
         if (sk > 64) sk = 64;
         if (sk < 1) sk = 1;
     }
     p->splitk = sk;
     return 0;
+}
+
+static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
+    const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk));
+    if (pl.cfg == 0) hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
+    else if (pl.cfg == 1) hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1, 2, 3>), grid, dim3(CTHREADS), 0, st, P);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<2, 2, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
 }
 
 template <int KIND>
@@ -545,7 +785,8 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
         P.out = out_raw;
         P.slab_stride = 0;
     }
-    if (d->kind == RNR_CONV3x3_REFLECT) launch_kind<0>(pl, P, st);
+    if (pl.halo) launch_halo(pl, P, st);
+    else if (d->kind == RNR_CONV3x3_REFLECT) launch_kind<0>(pl, P, st);
     else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_kind<1>(pl, P, st);
     else launch_kind<2>(pl, P, st);
     if (int e = check_launch("conv_mfma_kernel")) return e;

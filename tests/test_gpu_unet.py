@@ -86,7 +86,11 @@ CASES = [
     (2, 1, 8, 8, [64, 64], 32),        # transposed conv, concat input
     (2, 2, 4, 4, [512], 512),          # tiny map, deep K -> split-K + view-straddling tiles
     (0, 3, 2, 2, [32], 32),            # 2x2 maps: reflect on both sides, tiles straddle views
-    (0, 1, 64, 64, [112], 64),         # first-layer-like
+    (0, 1, 64, 64, [112], 64),         # first-layer-like (halo kernel, 32x8 tiles)
+    (0, 2, 32, 64, [64], 78),          # halo kernel, 256x96 config, two views, non-square
+    (0, 1, 32, 32, [64, 64], 128),     # halo kernel, 32x4 tiles, skip concat
+    (0, 1, 64, 64, [256], 256),        # halo kernel + split-K over channel chunks
+    (0, 2, 8, 32, [32], 32),           # halo kernel: map exactly one tile high
 ]
 
 
