@@ -332,34 +332,44 @@ conv_mfma_kernel(const ConvParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 stride-1 convolutions on maps at least 32 pixels wide: LDS halo reuse.
+// LDS-halo kernels (maps whose output is at least 32 pixels wide).
 //
-// A workgroup owns a 32 x TH output tile (TH = 8 or 4).  For every 16-channel chunk it stages the (TH+2) x 34 input
-// halo ONCE in LDS (reflection padding, the producer's BatchNorm/bias/activation and the skip concat applied on the
-// way in) and runs all nine taps from it: for tap (ky,kx) the MFMA A operand of output row y, lane x is the halo
-// element (y+ky, x+kx) — 32 consecutive LDS dwords, conflict-free.  Compared with the tap-by-tap gather of
-// conv_mfma_kernel this cuts the L2->LDS traffic, the global-load / ds_write instruction count and the prologue math
-// of the A operand by 256*9/340 = 6.8x (TH = 8); the MFMA work is identical.
-// Pipeline step = one (chunk, tap): weights of the next step and one float4 of the next chunk's halo are fetched to
+// A workgroup owns a 32 x TH tile of output pixels (TH = 8 or 4).  For every 16-channel chunk it stages the input
+// HALO of that tile once in LDS — reflection padding (or the zero border of the transposed conv), the producer's
+// BatchNorm/bias/activation and the skip concat are applied on the way in — and runs ALL taps of the chunk from it.
+// For a tap the MFMA A operand of output row y, lane x is one halo element at a lane-consecutive LDS address:
+//   KIND 0  3x3 s1          halo (TH+2) x 34,   element (y+ky, x+kx)                       9 taps
+//   KIND 1  4x4 s2          halo (2TH+2) x 66,  element (2y+ky, 2x+kx); columns are stored de-interleaved
+//                           (even | odd) so that the stride-2 access stays conflict-free    16 taps
+//   KIND 2  convT 4x4 s2    halo (TH+2) x 34 of the INPUT, zero outside; one output parity class per workgroup,
+//                           element (y+oy(ty), x+ox(tx))                                   4 taps
+// Versus the tap-by-tap gather of conv_mfma_kernel the L2->LDS traffic, the global-load / ds_write instruction count
+// and the prologue math of the A operand drop by taps*256/halo = 6.8x / 3.1x / 3.0x; the MFMA work is identical.
+// Pipeline step = one (chunk, tap): the next step's weights and a slice of the next chunk's halo are fetched to
 // registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
 // ------------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 __global__ void __launch_bounds__(CTHREADS)
-conv3x3_halo_kernel(const ConvParams P) {
+conv_halo_kernel(const ConvParams P) {
     constexpr int TW = 32, TH = WAVES_M * WM;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
-    constexpr int LDA = HP;                               // 340 / 204: 4*LDA % 32 == 16 -> <= 2-way ds_write conflicts
-    constexpr int ASLOTS = HP * 4;                        // float4 slots of one halo chunk
+    constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
+    constexpr int HWD = KIND == 1 ? 2 * TW + 2 : TW + 2;   // halo width  34 / 66
+    constexpr int HHT = KIND == 1 ? 2 * TH + 2 : TH + 2;   // halo height
+    constexpr int HP = HWD * HHT;
+    constexpr int LDA = HP;                                // 340, 204, 660: 4*LDA % 32 == 16 -> <= 2-way ds_write conflicts
+    constexpr int ASLOTS = HP * 4;                         // float4 slots of one halo chunk
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
+    constexpr int APS = (APT + TAPS - 1) / TAPS;           // halo float4 fetched per pipeline step
     constexpr int LDB = BN + 4;
     constexpr int BQ = BK * BN / 4;
     constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
-    static_assert(APT <= 9, "halo loads are spread over the nine tap steps");
+    static_assert(LDA % 8 == 4, "LDA chosen for <= 2-way ds_write bank conflicts");
     static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BK*LDA]
+    float* Bs = smem + 2 * BK * LDA;        // [2][BK*LDB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -368,9 +378,12 @@ conv3x3_halo_kernel(const ConvParams P) {
     const int wn0 = wave_n * WN * 32;
     int mt_, nt_, z_;
     tile_coords(P, mt_, nt_, z_);
-    const int split = z_;
+    const int par = (KIND == 2) ? (z_ & 3) : 0;
+    const int split = (KIND == 2) ? (z_ >> 2) : z_;
+    const int py = par >> 1, px = par & 1;
     const int n0 = nt_ * BN;
-    const int tiles_x = P.W / TW, tiles_y = P.H / TH;
+    // tile grid lives in the GEMM row space: output pixels (KIND 0/1) or input pixels of a parity class (KIND 2)
+    const int tiles_x = P.Wo / TW, tiles_y = P.Ho / TH;
     const int n = mt_ / (tiles_x * tiles_y);
     const int trem = mt_ - n * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
@@ -382,12 +395,19 @@ conv3x3_halo_kernel(const ConvParams P) {
     for (int j = 0; j < APT; j++) {
         const int s = tid + CTHREADS * j;
         const int hp = s >> 2;
-        spix[j] = -1;
-        sdst[j] = (4 * q) * LDA + hp;
+        spix[j] = -1;           // -1: slot beyond the halo;  -2: zero border (KIND 2)
+        sdst[j] = 0;
         if (s < ASLOTS) {
             const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int iy = reflect1(y0 - 1 + hy, P.H), ix = reflect1(x0 - 1 + hx, P.W);
-            spix[j] = (n * P.H + iy) * P.W + ix;
+            int iy, ix, col = hx;
+            if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
+            else if (KIND == 1) {
+                iy = reflect1(2 * y0 - 1 + hy, P.H); ix = reflect1(2 * x0 - 1 + hx, P.W);
+                col = (hx & 1) * (HWD / 2) + (hx >> 1);                 // de-interleave even | odd columns
+            } else { iy = y0 - 1 + hy; ix = x0 - 1 + hx; }
+            sdst[j] = (4 * q) * LDA + hy * HWD + col;
+            if (KIND == 2 && (iy < 0 || iy >= P.H || ix < 0 || ix >= P.W)) spix[j] = -2;
+            else spix[j] = (n * P.H + iy) * P.W + ix;
         }
     }
 
@@ -416,17 +436,21 @@ conv3x3_halo_kernel(const ConvParams P) {
         return v;
     };
     auto store_a = [&](const ChunkSrc& cs, float4 v, int j, int buf) {
-        if (spix[j] >= 0) {
-            float* a = &As[buf][sdst[j]];
-            a[0 * LDA] = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
-            a[1 * LDA] = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
-            a[2 * LDA] = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
-            a[3 * LDA] = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
+        if (spix[j] != -1) {
+            float* a = As + buf * (BK * LDA) + sdst[j];
+            if (KIND == 2 && spix[j] == -2) {       // zero border of the transposed conv: exactly 0, not act(shift)
+                a[0 * LDA] = 0.f; a[1 * LDA] = 0.f; a[2 * LDA] = 0.f; a[3 * LDA] = 0.f;
+            } else {
+                a[0 * LDA] = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
+                a[1 * LDA] = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
+                a[2 * LDA] = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
+                a[3 * LDA] = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
+            }
         }
     };
     float4 breg[BPT];
     auto load_b = [&](int c, int t) {
-        const size_t krow0 = ((size_t)t * nchunks + c) * BK;
+        const size_t krow0 = ((size_t)(par * TAPS + t) * nchunks + c) * BK;
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
             const int idx = tid + CTHREADS * b;
@@ -445,7 +469,7 @@ conv3x3_halo_kernel(const ConvParams P) {
             const int idx = tid + CTHREADS * b;
             if (idx < BQ) {
                 const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
-                *reinterpret_cast<float4*>(&Bs[buf][kr * LDB + 4 * c4]) = breg[b];
+                *reinterpret_cast<float4*>(Bs + buf * (BK * LDB) + kr * LDB + 4 * c4) = breg[b];
             }
         }
     };
@@ -470,25 +494,39 @@ conv3x3_halo_kernel(const ConvParams P) {
     for (int c = c_begin; c < c_end; c++) {
         const int abuf = (c - c_begin) & 1;
         const bool next_chunk = c + 1 < c_end;
-        ChunkSrc csn;
-        if (next_chunk) csn = chunk_src(c + 1);
+        ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
 #pragma unroll
-        for (int t = 0; t < 9; t++, step++) {
-            const bool more = next_chunk || t < 8;
+        for (int t = 0; t < TAPS; t++, step++) {
+            const bool more = next_chunk || t < TAPS - 1;
             if (more) {
-                if (t < 8) load_b(c, t + 1); else load_b(c + 1, 0);
+                if (t < TAPS - 1) load_b(c, t + 1); else load_b(c + 1, 0);
             }
-            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (next_chunk && t < APT) av = load_a(csn, t);
-            const int ky = t / 3, kx = t % 3;
-            const float* a_s = &As[abuf][(wave_m * WM + ky) * HWD + kx + l31];
-            const float* b_s = &Bs[step & 1][wn0 + l31];
+            float4 av[APS];
+#pragma unroll
+            for (int u = 0; u < APS; u++) {
+                const int j = t * APS + u;
+                av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (next_chunk && j < APT) av[u] = load_a(csn, j);
+            }
+            // LDS element of output row (wave_m*WM + i), lane x for this tap
+            int aoff;
+            if (KIND == 0) aoff = (wave_m * WM + t / 3) * HWD + (t % 3);
+            else if (KIND == 1) aoff = (2 * wave_m * WM + (t >> 2)) * HWD + ((t & 3) & 1) * (HWD / 2) + ((t & 3) >> 1);
+            else {
+                const int ty = t >> 1, tx = t & 1;
+                const int oy = py == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+                const int ox = px == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+                aoff = (wave_m * WM + oy) * HWD + ox;
+            }
+            constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;      // LDS distance between consecutive output rows
+            const float* a_s = As + abuf * (BK * LDA) + aoff + l31;
+            const float* b_s = Bs + (step & 1) * (BK * LDB) + wn0 + l31;
 #pragma unroll
             for (int s = 0; s < BK / 2; s++) {
                 const int k = 2 * s + h;
                 float a[WM], b[WN];
 #pragma unroll
-                for (int i = 0; i < WM; i++) a[i] = a_s[k * LDA + i * HWD];
+                for (int i = 0; i < WM; i++) a[i] = a_s[k * LDA + i * ROWSTEP];
 #pragma unroll
                 for (int j = 0; j < WN; j++) b[j] = b_s[k * LDB + 32 * j];
 #pragma unroll
@@ -497,7 +535,11 @@ conv3x3_halo_kernel(const ConvParams P) {
                     for (int j = 0; j < WN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-            if (next_chunk && t < APT) store_a(csn, av, t, abuf ^ 1);
+#pragma unroll
+            for (int u = 0; u < APS; u++) {
+                const int j = t * APS + u;
+                if (next_chunk && j < APT) store_a(csn, av[u], j, abuf ^ 1);
+            }
             if (more) store_b((step + 1) & 1);
             __syncthreads();
         }
@@ -511,7 +553,9 @@ conv3x3_halo_kernel(const ConvParams P) {
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const int x = x0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-            const size_t off = (((size_t)n * P.H + y) * P.W + x) * P.c_out_pad;
+            const size_t off = (KIND == 2)
+                ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
+                : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
 #pragma unroll
             for (int j = 0; j < WN; j++) {
                 const int col = n0 + wn0 + 32 * j + l31;
@@ -520,7 +564,7 @@ conv3x3_halo_kernel(const ConvParams P) {
         }
     }
     if (P.stats && P.splitk == 1) {
-        float* red = &As[0][0];   // [WAVES_M][BN][2]
+        float* red = As;   // [WAVES_M][BN][2]; LDS is free after the last barrier
 #pragma unroll
         for (int j = 0; j < WN; j++) {
             float s1 = 0.f, s2 = 0.f;
@@ -556,6 +600,20 @@ conv3x3_halo_kernel(const ConvParams P) {
             }
         }
     }
+}
+
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
+    constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32;
+    constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
+    constexpr size_t lds = (size_t)(2 * BK * HP + 2 * BK * (BN + 4)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {    // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
 }
 
 // out[m,c] = sum_s slab[s][m,c]; statistics per view.  grid (rows/64, c_out_pad/64), 256 threads.
@@ -671,9 +729,16 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     else { p->cfg = 2; p->bm = 128; p->bn = 128; }
     p->mtiles = (p->M + p->bm - 1) / p->bm;
     p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
-    const int th = p->bm / 32;       // halo kernel: 32 x th pixel tiles (all tile pixels must be inside the map)
-    p->halo = (d->kind == RNR_CONV3x3_REFLECT && W % 32 == 0 && H % th == 0) ? 1 : 0;
-    if (p->halo) p->mtiles = N * (H / th) * (W / 32);
+    // halo kernels: 32 x th tiles of the GEMM row space, all tile pixels inside the map.  The 4x4-s2 halo only fits
+    // LDS with th = 4 (128-row tiles).
+    if (d->kind == RNR_CONV4x4S2_REFLECT && p->cfg != 2 && p->Wo % 32 == 0 && p->Ho % 4 == 0) {
+        p->cfg = 2; p->bm = 128; p->bn = 128;
+        p->mtiles = (p->M + p->bm - 1) / p->bm;
+        p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+    }
+    const int th = p->bm / 32;
+    p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
+    if (p->halo) p->mtiles = N * (p->Ho / th) * (p->Wo / 32);
     const long tiles = (long)p->mtiles * p->ntiles * p->par;
     int sk = 1;
     if (tiles < 256) {
@@ -689,11 +754,12 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     return 0;
 }
 
+template <int KIND>
 static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
-    const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk));
-    if (pl.cfg == 0) hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
-    else if (pl.cfg == 1) hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1, 2, 3>), grid, dim3(CTHREADS), 0, st, P);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<2, 2, 2, 2>), grid, dim3(CTHREADS), 0, st, P);
+    const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
+    if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2>(grid, P, st);
+    else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 3>(grid, P, st);
+    else launch_halo_cfg<KIND, 2, 2, 2, 2>(grid, P, st);
 }
 
 template <int KIND>
@@ -785,7 +851,9 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
         P.out = out_raw;
         P.slab_stride = 0;
     }
-    if (pl.halo) launch_halo(pl, P, st);
+    if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
+    else if (pl.halo && d->kind == RNR_CONV4x4S2_REFLECT) launch_halo<1>(pl, P, st);
+    else if (pl.halo) launch_halo<2>(pl, P, st);
     else if (d->kind == RNR_CONV3x3_REFLECT) launch_kind<0>(pl, P, st);
     else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_kind<1>(pl, P, st);
     else launch_kind<2>(pl, P, st);

@@ -91,6 +91,12 @@ CASES = [
     (0, 1, 32, 32, [64, 64], 128),     # halo kernel, 32x4 tiles, skip concat
     (0, 1, 64, 64, [256], 256),        # halo kernel + split-K over channel chunks
     (0, 2, 8, 32, [32], 32),           # halo kernel: map exactly one tile high
+    (1, 1, 64, 64, [64], 128),         # 4x4 s2 halo kernel (de-interleaved columns)
+    (1, 2, 64, 128, [32], 16),         # 4x4 s2 halo kernel, narrow output forced onto the 128-column config
+    (1, 1, 128, 64, [128], 256),       # 4x4 s2 halo, two column tiles
+    (2, 1, 32, 32, [64, 64], 64),      # transposed conv halo kernel, 32x8 tiles, concat
+    (2, 2, 32, 64, [128], 128),        # transposed conv halo kernel, 32x4 tiles
+    (2, 1, 8, 32, [256], 78),          # transposed conv halo, 256x96 config, split-K
 ]
 
 
