@@ -27,15 +27,23 @@ constexpr int TILE = 16;
 constexpr int RTHREADS = 256;
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_CHUNK = RTHREADS * SCAN_ITEMS;
-constexpr int QCAP = 2048;
+constexpr int FLUSH_EVERY = 4;                          // scan steps between queue-level checks (one barrier each)
+constexpr int QCAP = (FLUSH_EVERY + 2) * SCAN_CHUNK;    // a flush is forced once more than 2 chunks are queued
+constexpr int STAGE = 128;                             // candidates staged in LDS per evaluation batch
 constexpr int STAGE_FLOATS = 24;
 
 struct __attribute__((aligned(8))) FaceBox {
     short xlo, xhi, ylo, yhi;  // inclusive pixel-index bounds, rows in the kernel's native (unflipped) order
 };
 // xlo == BOX_EXACT : bounding box not trustworthy, the exact tile test decides
-// xlo >  xhi       : never a candidate (back face, or entirely off-screen)
+// empty_box()     : never a candidate (back face, or entirely off-screen)
 constexpr short BOX_EXACT = -2;
+// a box that overlaps no tile under the interval test `lo <= t_hi && hi >= t_lo` (lo > every tile index, hi < 0)
+__host__ __device__ __forceinline__ FaceBox empty_box() {
+    FaceBox b;
+    b.xlo = 32767; b.xhi = -1; b.ylo = 32767; b.yhi = -1;
+    return b;
+}
 
 __device__ __forceinline__ bool backface(const float* f) {
     // rasterize_cuda_kernel.cu:40 / :111
@@ -77,7 +85,7 @@ face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ 
     }
     FaceBox box;
     if (backface(f)) {  // reference returns before writing: caller's zero fill stays (rasterize.py:163)
-        box.xlo = 1; box.xhi = 0; box.ylo = 1; box.yhi = 0;
+        box = empty_box();
         boxes[i] = box;
         if (GATHER) {
 #pragma unroll
@@ -124,7 +132,7 @@ face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ 
         lx = fmax(lx, 0.0); ly = fmax(ly, 0.0);
         hx = fmin(hx, (double)(is - 1)); hy = fmin(hy, (double)(is - 1));
         if (lx > hx || ly > hy) {
-            box.xlo = 1; box.xhi = 0; box.ylo = 1; box.yhi = 0;
+            box = empty_box();
         } else {
             box.xlo = (short)lx; box.xhi = (short)hx; box.ylo = (short)ly; box.yhi = (short)hy;
         }
@@ -170,8 +178,8 @@ template <int MODE>
 __global__ void __launch_bounds__(RTHREADS)
 raster_tile_kernel(const RasterParams P) {
     __shared__ int s_queue[QCAP];
-    __shared__ __attribute__((aligned(16))) float s_stage[RTHREADS * STAGE_FLOATS];
-    __shared__ int s_cnt[SCAN_ITEMS][RTHREADS / 64];
+    __shared__ __attribute__((aligned(16))) float s_stage[STAGE * STAGE_FLOATS];
+    __shared__ int s_qn;
 
     const int is = P.is, nf = P.nf;
     const int tiles_x = (is + TILE - 1) / TILE;
@@ -179,7 +187,7 @@ raster_tile_kernel(const RasterParams P) {
     const int bn = blockIdx.y;
     const int tx0 = (tile % tiles_x) * TILE, ty0 = (tile / tiles_x) * TILE;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const int xi = tx0 + (tid & (TILE - 1)), yi = ty0 + (tid >> 4);
     const bool in_img = (xi < is) && (yi < is);
     const int tx1 = min(tx0 + TILE - 1, is - 1), ty1 = min(ty0 + TILE - 1, is - 1);
@@ -195,11 +203,16 @@ raster_tile_kernel(const RasterParams P) {
     float best_z = P.far_;
     int best = -1;
     float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
-    int qn = 0;
 
-    auto process_queue = [&]() {
-        for (int s0 = 0; s0 < qn; s0 += RTHREADS) {
-            const int n = min(RTHREADS, qn - s0);
+    if (tid == 0) s_qn = 0;
+    __syncthreads();
+
+    // Evaluate the queued candidates.  The queue is NOT in face order (waves append independently), so the
+    // reference's "ascending faces, strict <" rule (cu:142-153) is applied as its order-free equivalent:
+    // smallest zp wins, equal zp -> smallest face index; a NaN zp never wins either way.
+    auto process_queue = [&](int qn) {
+        for (int s0 = 0; s0 < qn; s0 += STAGE) {
+            const int n = min(STAGE, qn - s0);
             if (tid < n) {
                 const int fn = s_queue[s0 + tid];
                 const float* f = faces + (size_t)fn * 9;
@@ -213,7 +226,6 @@ raster_tile_kernel(const RasterParams P) {
                 dst[3] = make_float4(fi[0], fi[1], fi[2], fi[3]);
                 dst[4] = make_float4(fi[4], fi[5], fi[6], fi[7]);
                 dst[5] = make_float4(fi[8], z0, z1, z2);
-                // slot 5.x..: fi8, z0, z1, z2 ; the face index itself is re-read from s_queue
             }
             __syncthreads();
             if (in_img) {
@@ -237,57 +249,66 @@ raster_tile_kernel(const RasterParams P) {
                     w0 /= wsum; w1 /= wsum; w2 /= wsum;
                     const float zp = 1.0f / (w0 / r5.y + w1 / r5.z + w2 / r5.w);   // cu:136
                     if (zp <= P.near_ || P.far_ <= zp) continue;                    // cu:137-139
-                    if (zp < best_z) {                                              // cu:142
+                    const int fn = s_queue[s0 + c];
+                    if (zp < best_z || (zp == best_z && best >= 0 && fn < best)) {  // cu:142, order-free form
                         best_z = zp;
-                        best = s_queue[s0 + c];
+                        best = fn;
                         bw0 = w0; bw1 = w1; bw2 = w2;
                     }
                 }
             }
             __syncthreads();
         }
-        qn = 0;
     };
 
-    for (int base = 0; base < nf; base += SCAN_CHUNK) {
-        bool keep[SCAN_ITEMS];
-        int pre[SCAN_ITEMS];
+    const int nsteps = (nf + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    FaceBox bx[SCAN_ITEMS];
+    auto fetch_boxes = [&](int step) {
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; j++) {
-            const int fn = base + j * RTHREADS + tid;
+            const int fn = step * SCAN_CHUNK + j * RTHREADS + tid;
+            FaceBox b = empty_box();
+            if (fn < nf) b = boxes[fn];
+            bx[j] = b;
+        }
+    };
+    fetch_boxes(0);
+    for (int step = 0; step < nsteps; step++) {
+        FaceBox cur[SCAN_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) cur[j] = bx[j];
+        if (step + 1 < nsteps) fetch_boxes(step + 1);          // next step's boxes are in flight during this step
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const int fn = step * SCAN_CHUNK + j * RTHREADS + tid;
+            const FaceBox b = cur[j];
             bool k = false;
-            if (fn < nf) {
-                const FaceBox b = boxes[fn];
-                const bool exact_only = (b.xlo == BOX_EXACT);
-                if (exact_only || (b.xlo <= tx1 && b.xhi >= tx0 && b.ylo <= ty1 && b.yhi >= ty0)) {
-                    const float* f = faces + (size_t)fn * 9;
-                    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
-                    k = !(edge_rejects_tile(x0, y0, x1, y1, t_xlo, t_xhi, t_ylo, t_yhi) ||
-                          edge_rejects_tile(x1, y1, x2, y2, t_xlo, t_xhi, t_ylo, t_yhi) ||
-                          edge_rejects_tile(x2, y2, x0, y0, t_xlo, t_xhi, t_ylo, t_yhi));
-                }
+            const bool exact_only = (b.xlo == BOX_EXACT);
+            if (fn < nf && (exact_only || (b.xlo <= tx1 && b.xhi >= tx0 && b.ylo <= ty1 && b.yhi >= ty0))) {
+                const float* f = faces + (size_t)fn * 9;
+                const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+                k = !(edge_rejects_tile(x0, y0, x1, y1, t_xlo, t_xhi, t_ylo, t_yhi) ||
+                      edge_rejects_tile(x1, y1, x2, y2, t_xlo, t_xhi, t_ylo, t_yhi) ||
+                      edge_rejects_tile(x2, y2, x0, y0, t_xlo, t_xhi, t_ylo, t_yhi));
             }
-            keep[j] = k;
             const unsigned long long bal = __ballot(k);
-            pre[j] = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_cnt[j][wave] = __popcll(bal);
-        }
-        __syncthreads();
-        int run = qn;
-#pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; j++) {
-#pragma unroll
-            for (int w = 0; w < RTHREADS / 64; w++) {
-                const int c = s_cnt[j][w];
-                if (w == wave && keep[j]) s_queue[run + pre[j]] = base + j * RTHREADS + tid;
-                run += c;
+            if (bal) {                                          // wave-uniform: most steps add nothing
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_qn, __popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (k) s_queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = fn;
             }
         }
-        qn = run;
-        __syncthreads();
-        if (qn > QCAP - SCAN_CHUNK) process_queue();
+        if ((step % FLUSH_EVERY) == FLUSH_EVERY - 1 || step == nsteps - 1) {
+            __syncthreads();
+            const int qn = s_qn;
+            if (qn > 2 * SCAN_CHUNK || step == nsteps - 1) {    // block-uniform
+                process_queue(qn);                             // ends with a barrier
+                if (tid == 0) s_qn = 0;
+                __syncthreads();
+            }
+        }
     }
-    if (qn > 0) process_queue();
 
     if (!in_img) return;
     const int yo = P.flip ? (is - 1 - yi) : yi;

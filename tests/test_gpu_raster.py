@@ -71,6 +71,19 @@ def test_random_soup_vs_oracle(S, nf, seed):
         assert (g['face_index_map'] >= 0).mean() > 0.3
 
 
+def test_back_faces_never_rasterize():
+    """Every face twice, once with reversed winding (what fill_back does, renderer.py:209-211): the culled copies
+    must never be picked, in particular not in tile (0,0) (regression: an 'empty' box that still overlapped tile 0)."""
+    from oracle import raster as oras
+    rng = np.random.RandomState(11)
+    f = rng.uniform(-1.2, 1.2, size=(1, 600, 3, 3)).astype(np.float32)
+    f[..., 2] = rng.uniform(0.5, 5.0, size=(1, 600, 3))
+    both = np.concatenate([f, f[:, :, ::-1, :]], 1)
+    g = oras.face_index_map(both, 48, 0.0, 1e5)
+    r = run_hip_raster(both, 48, 0.0, 1e5)
+    assert_same(r, g)
+
+
 def test_sphere_512_vs_oracle():
     """BASELINE config size: 65 536-face UV sphere at 512^2 (includes the zero-area pole faces)."""
     from oracle import raster as oras
