@@ -35,8 +35,8 @@ const char* rnr_last_error(void);
  * 1. neural_renderer.cuda.rasterize — drop-in for the pybind module (rasterize_cuda.cpp:124-191)
  * ===================================================================================================== */
 
-/* Bytes of scratch rnr_forward_face_index_map needs for (batch, num_faces). */
-size_t rnr_raster_workspace_bytes(int batch_size, int num_faces);
+/* Bytes of scratch rnr_forward_face_index_map needs for (batch, num_faces, image_size). */
+size_t rnr_raster_workspace_bytes(int batch_size, int num_faces, int image_size);
 
 /*
  * forward_face_index_map (rasterize_cuda.cpp:66-98 -> rasterize_cuda_kernel.cu:24-169, launch 595-650).
@@ -46,7 +46,7 @@ size_t rnr_raster_workspace_bytes(int batch_size, int num_faces);
  *   depth_map      [B, is, is]    caller pre-fills `far`          (rasterize.py:52)
  *   face_inv_map   [B, is, is, 3, 3] written when return_depth != 0 (may be NULL otherwise)
  *   faces_inv      [B, nf, 3, 3]  caller pre-fills 0              (rasterize.py:163)
- *   workspace      rnr_raster_workspace_bytes(B, nf) bytes of device scratch
+ *   workspace      rnr_raster_workspace_bytes(B, nf, is) bytes of device scratch
  * Rows are in the extension's native order (row 0 = bottom of the image); the vertical flip is done by the
  * Python layer (rasterize.py:307-321).  Only covered pixels are written.  Results are bit-identical to the
  * reference kernels evaluated in IEEE binary32 without FMA contraction.
@@ -109,7 +109,7 @@ typedef struct rnr_gbuffer {
     float* position_map_cam; /* [N,S,S,3] */
 } rnr_gbuffer;
 
-size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces);
+size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces, int image_size);
 
 /*
  * projected vertices -> per-face setup -> tiled z-resolve -> attribute interpolation, i.e.

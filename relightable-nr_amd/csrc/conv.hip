@@ -65,10 +65,12 @@ __device__ __forceinline__ int reflect1(int i, int n) {   // ReflectionPad2d(1)
     return i >= n ? 2 * n - 2 - i : i;
 }
 
+// act(v) = max(v, slope * v) with slope = 1 (none), 0.2 (LeakyReLU 0.2), 0 (ReLU): branch-free, wave-uniform slope
+__device__ __forceinline__ float act_slope(int act) {
+    return act == RNR_ACT_LRELU02 ? 0.2f : (act == RNR_ACT_RELU ? 0.0f : 1.0f);
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == RNR_ACT_LRELU02) return v > 0.0f ? v : 0.2f * v;
-    if (act == RNR_ACT_RELU) return fmaxf(v, 0.0f);
-    return v;
+    return fmaxf(v, act_slope(act) * v);
 }
 
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
@@ -349,7 +351,7 @@ conv_mfma_kernel(const ConvParams P) {
 // registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ void __launch_bounds__(CTHREADS)
+__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4) ? 3 : 1)
 conv_halo_kernel(const ConvParams P) {
     constexpr int TW = 32, TH = WAVES_M * WM;
     constexpr int BN = WAVES_N * WN * 32;

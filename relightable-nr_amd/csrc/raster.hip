@@ -153,6 +153,81 @@ __device__ __forceinline__ bool edge_rejects_tile(float xa, float ya, float xb, 
     return (p0 < q0) && (p0 < q1) && (p1 < q0) && (p1 < q1);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 1b. face-parallel binning: O(faces x tiles-per-face) instead of every tile scanning every face.
+//     Each kept face is appended (LDS-free, one global atomic per (face, tile)) to the candidate list of every tile
+//     whose exact tile test it survives.  Lists are unordered; the z-resolve is order-free.  Faces whose box is not
+//     trustworthy (BOX_EXACT) or spans many tiles go to a per-view "wide" list and are tested against all tiles by
+//     bin_wide_kernel with (face, tile) pairs spread over the whole grid.  A tile whose list overflows BIN_CAP
+//     falls back to scanning all boxes itself (raster_tile_kernel), so capacity never affects results.
+// ------------------------------------------------------------------------------------------------
+constexpr int BIN_CAP = 2048;
+constexpr int WIDE_TILES = 64;
+
+__device__ __forceinline__ bool face_may_touch_tile(const float* f, int tx, int ty, int is) {
+    const int tx0 = tx * TILE, ty0 = ty * TILE;
+    const int tx1 = min(tx0 + TILE - 1, is - 1), ty1 = min(ty0 + TILE - 1, is - 1);
+    const float xlo = pix_center(tx0, is), xhi = pix_center(tx1, is);
+    const float ylo = pix_center(ty0, is), yhi = pix_center(ty1, is);
+    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+    return !(edge_rejects_tile(x0, y0, x1, y1, xlo, xhi, ylo, yhi) || edge_rejects_tile(x1, y1, x2, y2, xlo, xhi, ylo, yhi) ||
+             edge_rejects_tile(x2, y2, x0, y0, xlo, xhi, ylo, yhi));
+}
+
+__device__ __forceinline__ void bin_append(int* tile_count, int* tile_list, int tile, int fn) {
+    const int slot = atomicAdd(tile_count + tile, 1);
+    if (slot < BIN_CAP) tile_list[(size_t)tile * BIN_CAP + slot] = fn;
+}
+
+__global__ void __launch_bounds__(256)
+bin_faces_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ boxes, int* __restrict__ tile_count,
+                 int* __restrict__ tile_list, int* __restrict__ wide_count, int* __restrict__ wide_list, int batch,
+                 int nf, int is) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * nf) return;
+    const int bn = (int)(i / nf), fn = (int)(i % nf);
+    const FaceBox b = boxes[i];
+    if (b.xlo != BOX_EXACT && b.xlo > b.xhi) return;                    // empty_box(): culled / off-screen
+    const int tiles_x = (is + TILE - 1) / TILE;
+    const int ntiles = tiles_x * tiles_x;
+    const int txa = max(b.xlo, (short)0) / TILE, txb = b.xhi / TILE, tya = max(b.ylo, (short)0) / TILE, tyb = b.yhi / TILE;
+    if (b.xlo == BOX_EXACT || (txb - txa + 1) * (tyb - tya + 1) > WIDE_TILES) {
+        const int pos = atomicAdd(wide_count + bn, 1);
+        wide_list[(size_t)bn * nf + pos] = fn;
+        return;
+    }
+    const float* f = faces + i * 9;
+    int* tc = tile_count + (size_t)bn * ntiles;
+    int* tl = tile_list + (size_t)bn * ntiles * BIN_CAP;
+    for (int ty = tya; ty <= tyb; ty++)
+        for (int tx = txa; tx <= txb; tx++)
+            if (face_may_touch_tile(f, tx, ty, is)) bin_append(tc, tl, ty * tiles_x + tx, fn);
+}
+
+__global__ void __launch_bounds__(256)
+bin_wide_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ boxes, int* __restrict__ tile_count,
+                int* __restrict__ tile_list, const int* __restrict__ wide_count, const int* __restrict__ wide_list,
+                int nf, int is) {
+    const int bn = blockIdx.y;
+    const int tiles_x = (is + TILE - 1) / TILE;
+    const int ntiles = tiles_x * tiles_x;
+    const long total = (long)wide_count[bn] * ntiles;
+    int* tc = tile_count + (size_t)bn * ntiles;
+    int* tl = tile_list + (size_t)bn * ntiles * BIN_CAP;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int fn = wide_list[(size_t)bn * nf + (int)(p / ntiles)];
+        const int t = (int)(p % ntiles);
+        const int tx = t % tiles_x, ty = t / tiles_x;
+        const FaceBox b = boxes[(size_t)bn * nf + fn];
+        if (b.xlo != BOX_EXACT) {   // a big but trustworthy box still prunes
+            const int tx0 = tx * TILE, ty0 = ty * TILE;
+            if (!(b.xlo <= tx0 + TILE - 1 && b.xhi >= tx0 && b.ylo <= ty0 + TILE - 1 && b.yhi >= ty0)) continue;
+        }
+        if (face_may_touch_tile(faces + ((size_t)bn * nf + fn) * 9, tx, ty, is)) bin_append(tc, tl, t, fn);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. tile kernel
 // ------------------------------------------------------------------------------------------------
@@ -160,6 +235,8 @@ struct RasterParams {
     const float* faces;      // [B,nf,9]
     const float* faces_inv;  // [B,nf,9]
     const FaceBox* boxes;    // [B,nf]
+    const int* tile_count;   // [B,ntiles]  candidates binned per tile (may exceed BIN_CAP: then the tile rescans)
+    const int* tile_list;    // [B,ntiles,BIN_CAP]
     int nf, is;
     float near_, far_;
     int flip;                // 1: write row (is-1-yi)
@@ -210,11 +287,11 @@ raster_tile_kernel(const RasterParams P) {
     // Evaluate the queued candidates.  The queue is NOT in face order (waves append independently), so the
     // reference's "ascending faces, strict <" rule (cu:142-153) is applied as its order-free equivalent:
     // smallest zp wins, equal zp -> smallest face index; a NaN zp never wins either way.
-    auto process_queue = [&](int qn) {
+    auto process_queue = [&](const int* ids, int qn) {
         for (int s0 = 0; s0 < qn; s0 += STAGE) {
             const int n = min(STAGE, qn - s0);
             if (tid < n) {
-                const int fn = s_queue[s0 + tid];
+                const int fn = ids[s0 + tid];
                 const float* f = faces + (size_t)fn * 9;
                 const float* fi = faces_inv + (size_t)fn * 9;
                 float4* dst = reinterpret_cast<float4*>(s_stage + tid * STAGE_FLOATS);
@@ -249,7 +326,7 @@ raster_tile_kernel(const RasterParams P) {
                     w0 /= wsum; w1 /= wsum; w2 /= wsum;
                     const float zp = 1.0f / (w0 / r5.y + w1 / r5.z + w2 / r5.w);   // cu:136
                     if (zp <= P.near_ || P.far_ <= zp) continue;                    // cu:137-139
-                    const int fn = s_queue[s0 + c];
+                    const int fn = ids[s0 + c];
                     if (zp < best_z || (zp == best_z && best >= 0 && fn < best)) {  // cu:142, order-free form
                         best_z = zp;
                         best = fn;
@@ -261,7 +338,12 @@ raster_tile_kernel(const RasterParams P) {
         }
     };
 
-    const int nsteps = (nf + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    // fast path: the candidate list built by the binning kernels; a list that overflowed is ignored and the
+    // tile scans every box itself (slow, same result)
+    const int ntiles_all = tiles_x * tiles_x;
+    const int binned = P.tile_count ? P.tile_count[(size_t)bn * ntiles_all + tile] : BIN_CAP + 1;
+    const int nsteps = binned <= BIN_CAP ? 0 : (nf + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (binned <= BIN_CAP) process_queue(P.tile_list + ((size_t)bn * ntiles_all + tile) * BIN_CAP, binned);
     FaceBox bx[SCAN_ITEMS];
     auto fetch_boxes = [&](int step) {
 #pragma unroll
@@ -272,7 +354,7 @@ raster_tile_kernel(const RasterParams P) {
             bx[j] = b;
         }
     };
-    fetch_boxes(0);
+    if (nsteps > 0) fetch_boxes(0);
     for (int step = 0; step < nsteps; step++) {
         FaceBox cur[SCAN_ITEMS];
 #pragma unroll
@@ -303,7 +385,7 @@ raster_tile_kernel(const RasterParams P) {
             __syncthreads();
             const int qn = s_qn;
             if (qn > 2 * SCAN_CHUNK || step == nsteps - 1) {    // block-uniform
-                process_queue(qn);                             // ends with a barrier
+                process_queue(s_queue, qn);                    // ends with a barrier
                 if (tid == 0) s_qn = 0;
                 __syncthreads();
             }
@@ -459,13 +541,42 @@ texture_sampling_kernel(const float* __restrict__ faces, const float* __restrict
 
 static size_t box_bytes(int batch, int nf) { return align_up((size_t)batch * nf * sizeof(FaceBox), 256); }
 static size_t face_bytes(int batch, int nf) { return align_up((size_t)batch * nf * 9 * sizeof(float), 256); }
+static int num_tiles(int is) { const int t = (is + TILE - 1) / TILE; return t * t; }
+// binning scratch: [tile_count B*ntiles | wide_count B] (zeroed every call) | tile_list | wide_list
+static size_t bin_counter_bytes(int batch, int is) { return align_up((size_t)batch * (num_tiles(is) + 1) * sizeof(int), 256); }
+static size_t bin_bytes(int batch, int nf, int is) {
+    return bin_counter_bytes(batch, is) + align_up((size_t)batch * num_tiles(is) * BIN_CAP * sizeof(int), 256) +
+           align_up((size_t)batch * nf * sizeof(int), 256);
+}
+
+// Runs the two binning kernels; fills P.tile_count / P.tile_list.
+static int run_binning(char* ws, const float* faces, const FaceBox* boxes, int batch, int nf, int is, RasterParams* P,
+                       hipStream_t st) {
+    const int ntiles = num_tiles(is);
+    int* tile_count = reinterpret_cast<int*>(ws);
+    int* wide_count = tile_count + (size_t)batch * ntiles;
+    int* tile_list = reinterpret_cast<int*>(ws + bin_counter_bytes(batch, is));
+    int* wide_list = reinterpret_cast<int*>(ws + bin_counter_bytes(batch, is) +
+                                            align_up((size_t)batch * ntiles * BIN_CAP * sizeof(int), 256));
+    RNR_HIP(hipMemsetAsync(tile_count, 0, (size_t)batch * (ntiles + 1) * sizeof(int), st));
+    const long total = (long)batch * nf;
+    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, boxes, tile_count,
+                       tile_list, wide_count, wide_list, batch, nf, is);
+    if (int e = check_launch("bin_faces_kernel")) return e;
+    hipLaunchKernelGGL(bin_wide_kernel, dim3(512, batch), dim3(256), 0, st, faces, boxes, tile_count, tile_list, wide_count,
+                       wide_list, nf, is);
+    if (int e = check_launch("bin_wide_kernel")) return e;
+    P->tile_count = tile_count;
+    P->tile_list = tile_list;
+    return 0;
+}
 
 }  // namespace rnr
 
 using namespace rnr;
 
-extern "C" size_t rnr_raster_workspace_bytes(int batch_size, int num_faces) {
-    return box_bytes(batch_size, num_faces);
+extern "C" size_t rnr_raster_workspace_bytes(int batch_size, int num_faces, int image_size) {
+    return box_bytes(batch_size, num_faces) + bin_bytes(batch_size, num_faces, image_size);
 }
 
 extern "C" int rnr_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
@@ -490,6 +601,8 @@ extern "C" int rnr_forward_face_index_map(const float* faces, int32_t* face_inde
     P.near_ = near_; P.far_ = far_; P.flip = 0;
     P.face_index_map = face_index_map; P.weight_map = weight_map; P.depth_map = depth_map;
     P.face_inv_map = return_depth ? face_inv_map : nullptr;
+    if (int e = run_binning(reinterpret_cast<char*>(workspace) + box_bytes(batch_size, num_faces), faces, boxes, batch_size,
+                            num_faces, image_size, &P, st)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<0>, dim3(tiles * tiles, batch_size), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<0>");
@@ -513,8 +626,8 @@ extern "C" int rnr_forward_texture_sampling(const float* faces, const float* tex
     return check_launch("texture_sampling_kernel");
 }
 
-extern "C" size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces) {
-    return box_bytes(num_views, num_faces) + 2 * face_bytes(num_views, num_faces);
+extern "C" size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces, int image_size) {
+    return box_bytes(num_views, num_faces) + 2 * face_bytes(num_views, num_faces) + bin_bytes(num_views, num_faces, image_size);
 }
 
 extern "C" int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, const float* pose,
@@ -544,6 +657,8 @@ extern "C" int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, c
     P.faces = faces; P.faces_inv = faces_inv; P.boxes = boxes; P.nf = nf; P.is = image_size;
     P.near_ = near_; P.far_ = far_; P.flip = 1;
     P.mesh = *mesh; P.gb = *out; P.pose = pose;
+    if (int e = run_binning(ws + box_bytes(num_views, nf) + 2 * face_bytes(num_views, nf), faces, boxes, num_views, nf,
+                            image_size, &P, st)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<1>, dim3(tiles * tiles, num_views), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<1>");

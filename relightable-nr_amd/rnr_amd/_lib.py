@@ -47,12 +47,12 @@ P = ctypes.POINTER
 SIGNATURES = {
     'rnr_abi_version': (c_int, []),
     'rnr_last_error': (ctypes.c_char_p, []),
-    'rnr_raster_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'rnr_raster_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'rnr_forward_face_index_map': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int,
                                                             c_int, c_void_p, c_void_p]),
     'rnr_forward_texture_sampling': (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'rnr_project_vertices': (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_void_p]),
-    'rnr_gbuffer_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'rnr_gbuffer_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'rnr_rasterize_gbuffer': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_float, P(RnrGbuffer),
                                       c_void_p, c_void_p]),
     'rnr_face_tangents': (c_int, [P(RnrMesh), c_void_p, c_void_p]),

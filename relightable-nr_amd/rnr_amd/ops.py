@@ -45,7 +45,7 @@ def forward_face_index_map(faces, face_index_map, weight_map, depth_map, face_in
     if return_depth:
         _chk(face_inv_map, 'face_inv_map')
     B, nf = faces.shape[0], faces.shape[1]
-    ws = torch.empty(L.rnr_raster_workspace_bytes(B, nf), dtype=torch.uint8, device=faces.device)
+    ws = torch.empty(L.rnr_raster_workspace_bytes(B, nf, int(image_size)), dtype=torch.uint8, device=faces.device)
     check(L.rnr_forward_face_index_map(_ptr(faces), _ptr(face_index_map), _ptr(weight_map), _ptr(depth_map),
                                        _ptr(face_inv_map if return_depth else None), _ptr(faces_inv), B, nf,
                                        int(image_size), float(near), float(far), int(return_rgb), int(return_alpha),
@@ -131,7 +131,7 @@ def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=Non
     if pose is not None:
         _chk(pose, 'pose')
     if workspace is None:
-        workspace = torch.empty(L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces), dtype=torch.uint8, device=v_uvz.device)
+        workspace = torch.empty(L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces, S), dtype=torch.uint8, device=v_uvz.device)
     check(L.rnr_rasterize_gbuffer(ctypes.byref(mesh.c), _ptr(v_uvz), _ptr(pose), N, S, float(near), float(far),
                                   ctypes.byref(gb), _ptr(workspace), _stream()))
     return out

@@ -53,7 +53,7 @@ class RNRPipeline:
         self._gb_maps = ['face_index_map', 'alpha', 'uv_map', 'normal_map']
         self._net_in = torch.empty(N, S, S, self.unet.in_c_pad, dtype=torch.float32, device=self.dev)
         self._image = torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev)
-        self._ws = torch.empty(ops._lib.load().rnr_gbuffer_workspace_bytes(N, self.mesh.num_faces), dtype=torch.uint8,
+        self._ws = torch.empty(ops._lib.load().rnr_gbuffer_workspace_bytes(N, self.mesh.num_faces, S), dtype=torch.uint8,
                                device=self.dev)
         for m in self._gb_maps:
             dt, tail = ops.GBUFFER_MAPS[m]

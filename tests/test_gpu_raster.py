@@ -84,6 +84,21 @@ def test_back_faces_never_rasterize():
     assert_same(r, g)
 
 
+def test_bin_overflow_falls_back_to_scan():
+    """> BIN_CAP (2048) candidates in one tile: that tile must rescan all boxes and still match bit for bit."""
+    from oracle import raster as oras
+    rng = np.random.RandomState(12)
+    S, nf = 64, 6000
+    f = np.zeros((1, nf, 3, 3), np.float32)
+    c = rng.uniform(-0.4, -0.1, size=(nf, 1, 2))                # all centres inside one 16x16 tile
+    f[0, :, :, :2] = c + rng.uniform(-0.08, 0.08, size=(nf, 3, 2))
+    f[0, :, :, 2] = rng.uniform(0.5, 5.0, size=(nf, 3))
+    f[0, :200, :, :2] = rng.uniform(-1.2, 1.2, size=(200, 3, 2))   # plus some faces elsewhere
+    g = oras.face_index_map(f, S, 0.0, 1e5)
+    r = run_hip_raster(f, S, 0.0, 1e5)
+    assert_same(r, g)
+
+
 def test_sphere_512_vs_oracle():
     """BASELINE config size: 65 536-face UV sphere at 512^2 (includes the zero-area pole faces)."""
     from oracle import raster as oras
