@@ -351,7 +351,7 @@ conv_mfma_kernel(const ConvParams P) {
 // registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4) ? 3 : 1)
+__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4) ? 3 : (KIND == 1 && WM * WN <= 4 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
     constexpr int TW = 32, TH = WAVES_M * WM;
     constexpr int BN = WAVES_N * WN * 32;
@@ -363,6 +363,10 @@ conv_halo_kernel(const ConvParams P) {
     constexpr int ASLOTS = HP * 4;                         // float4 slots of one halo chunk
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
     constexpr int APS = (APT + TAPS - 1) / TAPS;           // halo float4 fetched per pipeline step
+    // The 4x4-s2 halo (660 px) double-buffered would leave room for one workgroup per CU only (MFMA pipe 53 % busy,
+    // profiles/r01_pmc_per_kernel_v4): keep ONE LDS copy, carry the next chunk's halo in registers across the 16 taps
+    // and swap it in between chunks (one extra barrier per chunk) -> two workgroups per CU.
+    constexpr int ABUFS = KIND == 1 ? 1 : 2;
     constexpr int LDB = BN + 4;
     constexpr int BQ = BK * BN / 4;
     constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
@@ -370,8 +374,8 @@ conv_halo_kernel(const ConvParams P) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BK*LDA]
-    float* Bs = smem + 2 * BK * LDA;        // [2][BK*LDB]
+    float* As = smem;                       // [ABUFS][BK*LDA]
+    float* Bs = smem + ABUFS * BK * LDA;    // [2][BK*LDB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -494,9 +498,10 @@ conv_halo_kernel(const ConvParams P) {
     __syncthreads();
     int step = 0;
     for (int c = c_begin; c < c_end; c++) {
-        const int abuf = (c - c_begin) & 1;
+        const int abuf = ABUFS == 2 ? ((c - c_begin) & 1) : 0;
         const bool next_chunk = c + 1 < c_end;
         ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
+        float4 av_all[ABUFS == 1 ? APT : 1];
 #pragma unroll
         for (int t = 0; t < TAPS; t++, step++) {
             const bool more = next_chunk || t < TAPS - 1;
@@ -508,7 +513,10 @@ conv_halo_kernel(const ConvParams P) {
             for (int u = 0; u < APS; u++) {
                 const int j = t * APS + u;
                 av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (next_chunk && j < APT) av[u] = load_a(csn, j);
+                if (next_chunk && j < APT) {
+                    av[u] = load_a(csn, j);
+                    if (ABUFS == 1) av_all[j] = av[u];
+                }
             }
             // LDS element of output row (wave_m*WM + i), lane x for this tap
             int aoff;
@@ -537,12 +545,19 @@ conv_halo_kernel(const ConvParams P) {
                     for (int j = 0; j < WN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+            if (ABUFS == 2) {
 #pragma unroll
-            for (int u = 0; u < APS; u++) {
-                const int j = t * APS + u;
-                if (next_chunk && j < APT) store_a(csn, av[u], j, abuf ^ 1);
+                for (int u = 0; u < APS; u++) {
+                    const int j = t * APS + u;
+                    if (next_chunk && j < APT) store_a(csn, av[u], j, abuf ^ 1);
+                }
             }
             if (more) store_b((step + 1) & 1);
+            __syncthreads();
+        }
+        if (ABUFS == 1 && next_chunk) {     // every wave is past the last tap's reads: swap the next halo in
+#pragma unroll
+            for (int j = 0; j < APT; j++) store_a(csn, av_all[j], j, 0);
             __syncthreads();
         }
     }
@@ -608,7 +623,7 @@ template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32;
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds = (size_t)(2 * BK * HP + 2 * BK * (BN + 4)) * sizeof(float);
+    constexpr size_t lds = (size_t)((KIND == 1 ? 1 : 2) * BK * HP + 2 * BK * (BN + 4)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {    // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN>),
