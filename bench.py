@@ -33,7 +33,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--views-per-step', type=int, default=4, help='camera poses per GPU per step')
+    ap.add_argument('--views-per-step', type=int, default=8, help='camera poses per GPU per step')
     ap.add_argument('--img-size', type=int, default=512)
     ap.add_argument('--nf0', type=int, default=64)
     ap.add_argument('--tex-ch', type=int, default=24)
@@ -85,6 +85,22 @@ def cpu_baseline(sc, args, view_id, hip_image):
         parity = {'psnr_db_vs_oracle': orc.psnr(hip_image.cpu(), ref['image']),
                   'max_abs_err': float((hip_image.cpu() - ref['image']).abs().max())}
     return out, parity
+
+
+def pmc_traffic_per_step(views_per_step):
+    """HBM-side bytes of the conv kernels per step from the committed rocprofv3 PMC passes (profiles/README.md):
+    (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, scaled from the
+    profiled 4 views/step to this run's batch.  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel_*views4.json')))
+    if not files:
+        return None, None
+    prof = json.load(open(files[-1]))
+    steps = 3       # the PMC runs use --steps 2 --warmup 1
+    kb = sum(2.0 * v.get('FETCH_SIZE_total', 0.0) + v.get('WRITE_SIZE_total', 0.0) for k, v in prof.items() if 'conv_' in k)
+    if kb <= 0:
+        return None, None
+    return kb * 1024.0 / steps * (views_per_step / 4.0), os.path.basename(files[-1])
 
 
 def main():
@@ -155,6 +171,7 @@ def main():
     achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic_per_step(V)
         res = {
             'metric': 'rendered frames/sec at %dx%d (material_sphere-like synthetic scene), full HIP RNR path'
                       % (args.img_size, args.img_size),
@@ -166,9 +183,10 @@ def main():
                                    'levels, U-Net %d->%d nf0=%d' % (args.img_size, args.img_size, args.tex_ch, sc['c_in'],
                                                                    3 * sc['n_rays'], args.nf0),
                        'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (%d launches/step, U-Net stage incl. bn_finalize)' % n_conv,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (%d conv launches/step; HIP events bracket the U-Net stage incl. bn_finalize + split-K reduce)' % n_conv,
                          'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/step (HBM-side, PMC)',
+                         'traffic_source': traffic_src,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms},
         }
         if not args.no_cpu_baseline and world == 1:
