@@ -52,7 +52,7 @@ def build_scene(args):
         'textures': testing.synthetic_textures(512, args.tex_ch, 4, 0),
         'unet_sd': testing.unet_state_dict(c_in, 3 * n_rays, args.nf0, 5, 0),
         'pivots_spec': ps, 'pivots_diff': pd,
-        'lp': testing.synthetic_light_probe(100, 200, 2),
+        'sh_coeff': torch.from_numpy(scene.synthetic_sh_coeff(2, 10, 1)),        # LightingSH coeff [2,121,3], lmax 10
         'c_in': c_in, 'n_rays': n_rays,
     }
 
@@ -74,7 +74,9 @@ def cpu_baseline(sc, args, view_id, hip_image):
     views = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [view_id]).items()}
     mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
     t0 = time.time()
-    ref = orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'],
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]                   # network.py:622-627
+    ref = orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'],
                            sc['pivots_diff'])
     dt = time.time() - t0
     out = {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
@@ -120,7 +122,7 @@ def main():
     sc = build_scene(args)
     V = args.views_per_step
     pipe = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'],
-                       sc['lp'], nf0=args.nf0, max_views=V, device=dev)
+                       None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10)
     # pose slices: step s, rank r renders spiral views (s*world + r)*V ... +V  (mod 720)
     n_total = (args.steps + args.warmup) * world * V
     ids = (np.arange(n_total) * 7) % 720

@@ -17,14 +17,16 @@ from .unet import UNetPlan
 
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
-                 sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None):
+                 sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
         textures: list of [1,S_l,S_l,C] tensors (TextureMapper.textures, network.py:43-57)
         unet_state_dict: RenderingNet.state_dict() of the reference (keys `net.*`)
         pivots_spec / pivots_diff: RaySampler.pivots_dir buffers [3,R]
-        lp: environment map [1,Hl,Wl,3] or [Hl,Wl,3] (LightingSH.reconstruct_lp output)
+        lp: environment map [1,Hl,Wl,3] or [Hl,Wl,3] (LightingSH.reconstruct_lp output); may be None when
+            sh_coeff [L,(lmax+1)^2,3] is given: then the probe is reconstructed from the coefficients on every call
+            (like `lighting_model(lighting_idx, is_lp=True)` inside RayRenderer.forward, network.py:494-495)
         """
         self.dev = torch.device(device)
         self.S = int(img_size)
@@ -47,7 +49,14 @@ class RNRPipeline:
         self.max_views = int(max_views)
         self.unet = UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
                              (self.S, self.S), self.max_views, self.dev)
-        self.set_light_probe(lp)
+        self.sh_lighting, self.sh_coeff = None, None
+        if sh_coeff is not None:
+            from .lighting import SHLighting
+            self.sh_lighting = SHLighting(sh_lmax, self.dev)
+            self.sh_coeff = torch.as_tensor(sh_coeff, dtype=torch.float32).to(self.dev)
+            self.lp = None
+        else:
+            self.set_light_probe(lp)
         N, S = self.max_views, self.S
         self._gb = {}
         self._gb_maps = ['face_index_map', 'alpha', 'uv_map', 'normal_map']
@@ -58,14 +67,13 @@ class RNRPipeline:
         for m in self._gb_maps:
             dt, tail = ops.GBUFFER_MAPS[m]
             self._gb[m] = torch.empty((N, S, S) + tail, dtype=dt, device=self.dev)
-        self.mesh.tangents()
         self.last = {}
 
     def set_light_probe(self, lp):
         lp = torch.as_tensor(lp, dtype=torch.float32)
         self.lp = lp.reshape(lp.shape[-3], lp.shape[-2], 3).contiguous().to(self.dev)
 
-    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False):
+    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False, lighting_idx=0):
         """proj/proj_inv/R_inv [N,3,3], pose [N,4,4] device float32 -> image [N,3,S,S] (a view into a reused buffer)."""
         N = proj.shape[0]
         if N > self.max_views:
@@ -77,11 +85,13 @@ class RNRPipeline:
         gb = {m: self._gb[m][:N] for m in self._gb_maps}
         ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
                               workspace=self._ws)
+        self.mesh._tangents = None          # per-face tangents recomputed per call, as get_TBN_map does (render.py:135-150)
+        lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
         sh = ops.shade_inputs(gb, self.mesh, proj_inv.contiguous(), R_inv.contiguous(), self.textures,
                               self.pivots_spec, self.pivots_diff, self.sh_start_ch, c_pad=self.unet.in_c_pad,
                               net_in=self._net_in[:N])
         raw = self.unet.forward(sh['net_in'], N)
-        img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], self.lp, self.n_spec, self.n_diff,
+        img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff,
                              albedo_diff_ch=0, albedo_spec_ch=3, image=self._image[:N])
         if keep_intermediates:
             self.last = {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}

@@ -102,3 +102,30 @@ def test_host_helpers_match_oracle():
     assert np.allclose(misc.interpolate_bilinear_np(data, x, y), ref, atol=1e-6)
     azi, ele = camera.get_spiral()
     assert azi.shape == (720,) and abs(azi[1] + 2.0) < 1e-9 and abs(ele[1] - 0.125) < 1e-9
+
+
+def test_view_dataset_matches_reference(golden, tmp_path):
+    """calib.mat -> (proj, pose, proj_inv, R_inv, ...) vs the reference's ViewDataset.read_view for every sampling
+    pattern."""
+    import numpy as np
+    import scipy.io
+    import dataio
+    g = golden('dataio_views')
+    calib = {k[6:]: g[k] for k in g.files if k.startswith('calib:')}
+    fp = str(tmp_path / 'calib.mat')
+    scipy.io.savemat(fp, calib)
+    for pat in ['all', 'skip_3', 'first_5', 'after_6', 'skipinv_3', 'filter', 'only_2']:
+        ds = dataio.ViewDataset(root_dir=str(tmp_path), calib_path=fp, calib_format='convert', img_size=[64, 96],
+                                sampling_pattern=pat, load_img=False, load_precompute=False)
+        assert len(ds) == int(g[pat + ':num']), pat
+        ds.buffer_all()
+        for i in range(len(ds)):
+            v = ds[i][0]
+            again = ds.read_view(i)                    # pure: a second call gives the same values
+            for key in ['proj_orig', 'proj', 'pose', 'dist_coeffs', 'offset', 'scale', 'view_dir', 'proj_inv', 'R_inv']:
+                ref = g[pat + ':' + key][i]
+                assert v[key].dtype == torch.float32
+                assert np.allclose(v[key].numpy(), ref, rtol=1e-6, atol=1e-6), (pat, i, key)
+                assert torch.equal(v[key], again[key])
+    with pytest.raises(NotImplementedError):
+        dataio.ViewDataset(str(tmp_path), fp, 'convert', [64, 64], 'all', load_img=True)

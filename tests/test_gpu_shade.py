@@ -148,3 +148,24 @@ def test_ray_render_golden(golden):
         & (lt.permute(0, 3, 4, 1, 2).reshape(N, H, W, -1) > 0.01).all(-1)
     d = (img.cpu() - T(g['out'])).abs().permute(0, 2, 3, 1)[interior]
     assert d.numel() > 0 and d.max() < 2e-3, d.max()
+
+
+def test_lighting_front_end_vs_oracle():
+    """Env map -> 4096 bilinear samples -> SH (lmax 10) projection -> 100x200 reconstruction (config 5's lighting
+    path; network.py:665-672, 694-699, 622-627) vs the oracle."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import lighting, scene, testing
+    env = testing.synthetic_light_probe(160, 320, 5)[0]
+    l_dir = T(scene.sphere_samples(4096)).t().contiguous()
+    coeff, samples, basis = lighting.envmap_to_sh(env.to(DEV), l_dir.to(DEV), 10)
+    uv = orc.spherical_mapping(l_dir)
+    ref_samples = orc.interpolate_bilinear(env, (uv[0] * 320.0).clamp(max=319), (uv[1] * 160.0).clamp(max=159))
+    assert torch.allclose(samples.cpu(), ref_samples, atol=2e-5)
+    ref_basis = torch.from_numpy(orc.sh_basis(10, l_dir.t().numpy()).astype(np.float32))
+    ref_coeff = orc.fit_sh_coeff(ref_samples, ref_basis)
+    assert torch.allclose(coeff.cpu(), ref_coeff, atol=2e-4)
+    shl = lighting.SHLighting(10, DEV)
+    lp = shl.light_probe(coeff)
+    ref_lp = orc.reconstruct_lp(ref_coeff, torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32)))
+    assert lp.shape == (100, 200, 3)
+    assert torch.allclose(lp.cpu(), ref_lp, atol=5e-4)
