@@ -325,6 +325,42 @@ shade_inputs_kernel(const ShadeParams P) {
 // Ray renderer: 32 lanes per pixel (one ray each), 16-lane segmented shuffle reductions.
 // lane layout inside a 32-lane half: lanes 0..15 -> specular rays 0..15, lanes 16..31 -> diffuse rays 0..15
 // ------------------------------------------------------------------------------------------------
+// Polynomial atan2 / acos for the fused ray renderer (max abs error 3e-8 / 8e-8 rad, i.e. float rounding level; the
+// uv they feed is only used to pick env-map taps).  ocml's atan2f/acosf cost ~100 instructions each and made this
+// kernel transcendental-bound (26 rays per pixel).  The stand-alone ray-sampler operator keeps the ocml versions.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const float s = a * a;
+    float p = 0.002899040700867772f;
+    p = p * s - 0.01637016236782074f;
+    p = p * s + 0.04338274151086807f;
+    p = p * s - 0.07582952827215195f;
+    p = p * s + 0.10688958317041397f;
+    p = p * s - 0.14219146966934204f;
+    p = p * s + 0.19995006918907166f;
+    p = p * s - 0.3333321213722229f;
+    p = p * s + 1.0f;
+    float r = p * a;
+    if (ay > ax) r = 1.57079632679489662f - r;
+    if (x < 0.0f) r = 3.14159265358979324f - r;
+    return y < 0.0f ? -r : r;
+}
+__device__ __forceinline__ float fast_acosf(float x) {
+    const float ax = fminf(fabsf(x), 1.0f);
+    float p = -0.001102376147173345f;
+    p = p * ax + 0.006096228025853634f;
+    p = p * ax - 0.01627347804605961f;
+    p = p * ax + 0.03031114861369133f;
+    p = p * ax - 0.049957286566495895f;
+    p = p * ax + 0.08893882483243942f;
+    p = p * ax - 0.2145957499742508f;
+    p = p * ax + 1.570796251296997f;
+    const float r = sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979324f - r : r;
+}
+
 struct RayParams {
     const float* unet_raw; int c_out_pad;
     const float* bias;
@@ -344,59 +380,85 @@ __device__ __forceinline__ float seg16_sum(float v) {
     return v;
 }
 
+constexpr int RR_PIX = 4;     // pixels per lane: independent load chains in flight (the kernel is latency-bound)
+
 __global__ void __launch_bounds__(256)
 ray_render_kernel(const RayParams P) {
     const long gl = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long pix = gl >> 5;
+    const long grp = gl >> 5;                 // a 32-lane half-wave owns RR_PIX consecutive pixels
     const int sub = (int)(gl & 31);
     const bool is_diff = sub >= 16;
     const int rr = sub & 15;
-    const bool live = (pix < P.npix) && (is_diff ? rr < P.n_diff : rr < P.n_spec);
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    if (live) {
-        const int r = is_diff ? P.n_spec + rr : rr;
-        const float a = P.alpha[pix];
-        const float* d = P.net_in + pix * P.c_pad + 3 * r;
-        const float dx = d[0], dy = d[1], dz = d[2];
-        // rays_uv (render.py:96-102; network.py:469-470)
-        float u = atan2f(dz, dx) * 0.5f / RNR_PI_F + 0.5f;
-        float v = acosf(dy) * 1.0f / RNR_PI_F;
-        const float bg = (a == 0.0f) ? 1.0f : 0.0f;
-        u = u * a - bg;
-        v = v * a - bg;
-        // env-map taps (network.py:497; misc.py:5-42): clamp(max=) only, then the validity mask zeroes uv=-1
-        const float x = fminf(u * (float)P.lp_w, (float)(P.lp_w - 1));
-        const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
-        const Taps t = bilinear_taps(x, y, P.lp_w, P.lp_h);
-        const float* l00 = P.lp + ((size_t)t.y0 * P.lp_w + t.x0) * 3;
-        const float* l10 = P.lp + ((size_t)t.y1 * P.lp_w + t.x0) * 3;
-        const float* l01 = P.lp + ((size_t)t.y0 * P.lp_w + t.x1) * 3;
-        const float* l11 = P.lp + ((size_t)t.y1 * P.lp_w + t.x1) * 3;
-        const float* y_raw = P.unet_raw + pix * P.c_out_pad + 3 * r;
-        const float* b = P.bias + 3 * r;
+    const bool ray_live = is_diff ? rr < P.n_diff : rr < P.n_spec;
+    const int r = is_diff ? P.n_spec + rr : rr;
+    const long pix0 = grp * RR_PIX;
+    float dx[RR_PIX], dy[RR_PIX], dz[RR_PIX], al[RR_PIX], y0[RR_PIX], y1[RR_PIX], y2[RR_PIX];
+    bool live[RR_PIX];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float col = l00[c] * t.w00 + l10[c] * t.w10 + l01[c] * t.w01 + l11[c] * t.w11;
-            const float lt = (tanhf(y_raw[c] + b[c]) * 0.5f + 0.5f) * 2.0f;   // network.py:253; test_rnr.py:359
-            const float prod = lt * col;
-            if (c == 0) c0 = prod; else if (c == 1) c1 = prod; else c2 = prod;
+    for (int k = 0; k < RR_PIX; k++) {        // all global loads of the RR_PIX pixels are issued before any is used
+        const long pix = pix0 + k;
+        live[k] = ray_live && pix < P.npix;
+        dx[k] = dy[k] = dz[k] = al[k] = y0[k] = y1[k] = y2[k] = 0.f;
+        if (live[k]) {
+            const float* d = P.net_in + pix * P.c_pad + 3 * r;
+            const float* yr = P.unet_raw + pix * P.c_out_pad + 3 * r;
+            dx[k] = d[0]; dy[k] = d[1]; dz[k] = d[2];
+            y0[k] = yr[0]; y1[k] = yr[1]; y2[k] = yr[2];
+            al[k] = P.alpha[pix];
         }
     }
-    c0 = seg16_sum(c0); c1 = seg16_sum(c1); c2 = seg16_sum(c2);
-    // lane 0 of each 16-lane segment holds its segment's sum; bring the diffuse sum to the pixel's first lane
-    const float d0 = __shfl_down(c0, 16, 64), d1 = __shfl_down(c1, 16, 64), d2 = __shfl_down(c2, 16, 64);
-    if (sub == 0 && pix < P.npix) {
-        const float* ni = P.net_in + pix * P.c_pad + 3 * (P.n_spec + P.n_diff) + 6;
-        const float inv_s = 1.0f / (float)P.n_spec;
-        const long n = pix / P.hw, rem = pix % P.hw;
-        float o[3] = {c0, c1, c2}, dd[3] = {d0, d1, d2};
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (ray_live) { b0 = P.bias[3 * r + 0]; b1 = P.bias[3 * r + 1]; b2 = P.bias[3 * r + 2]; }
+    Taps tp[RR_PIX];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float out = ni[P.alb_spec_ch + c] * (o[c] / (float)P.n_spec);
-            if (P.n_diff > 0) out = out + ni[P.alb_diff_ch + c] * (dd[c] / (float)P.n_diff);
-            P.image[(n * 3 + c) * P.hw + rem] = out;
+    for (int k = 0; k < RR_PIX; k++) {
+        // rays_uv (render.py:96-102; network.py:469-470)
+        float u = fast_atan2f(dz[k], dx[k]) * 0.5f / RNR_PI_F + 0.5f;
+        float v = fast_acosf(dy[k]) * 1.0f / RNR_PI_F;
+        const float bg = (al[k] == 0.0f) ? 1.0f : 0.0f;
+        u = u * al[k] - bg;
+        v = v * al[k] - bg;
+        // env-map taps (network.py:497; misc.py:5-42): clamp(max=) only, then the validity mask zeroes uv = -1
+        const float x = fminf(u * (float)P.lp_w, (float)(P.lp_w - 1));
+        const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
+        tp[k] = bilinear_taps(x, y, P.lp_w, P.lp_h);
+    }
+    float c0[RR_PIX], c1[RR_PIX], c2[RR_PIX];
+#pragma unroll
+    for (int k = 0; k < RR_PIX; k++) {
+        c0[k] = c1[k] = c2[k] = 0.f;
+        if (live[k]) {
+            const Taps& t = tp[k];
+            const float* l00 = P.lp + ((size_t)t.y0 * P.lp_w + t.x0) * 3;
+            const float* l10 = P.lp + ((size_t)t.y1 * P.lp_w + t.x0) * 3;
+            const float* l01 = P.lp + ((size_t)t.y0 * P.lp_w + t.x1) * 3;
+            const float* l11 = P.lp + ((size_t)t.y1 * P.lp_w + t.x1) * 3;
+            const float col0 = l00[0] * t.w00 + l10[0] * t.w10 + l01[0] * t.w01 + l11[0] * t.w11;
+            const float col1 = l00[1] * t.w00 + l10[1] * t.w10 + l01[1] * t.w01 + l11[1] * t.w11;
+            const float col2 = l00[2] * t.w00 + l10[2] * t.w10 + l01[2] * t.w01 + l11[2] * t.w11;
+            // network.py:253 tanh; test_rnr.py:359 (y*0.5+0.5)*2
+            c0[k] = (tanhf(y0[k] + b0) * 0.5f + 0.5f) * 2.0f * col0;
+            c1[k] = (tanhf(y1[k] + b1) * 0.5f + 0.5f) * 2.0f * col1;
+            c2[k] = (tanhf(y2[k] + b2) * 0.5f + 0.5f) * 2.0f * col2;
         }
-        (void)inv_s;
+    }
+#pragma unroll
+    for (int k = 0; k < RR_PIX; k++) {
+        const float s0 = seg16_sum(c0[k]), s1 = seg16_sum(c1[k]), s2 = seg16_sum(c2[k]);
+        // lane 0 of each 16-lane segment holds its segment's sum; bring the diffuse sum to the group's first lane
+        const float d0 = __shfl_down(s0, 16, 64), d1 = __shfl_down(s1, 16, 64), d2 = __shfl_down(s2, 16, 64);
+        const long pix = pix0 + k;
+        if (sub == 0 && pix < P.npix) {
+            const float* ni = P.net_in + pix * P.c_pad + 3 * (P.n_spec + P.n_diff) + 6;
+            const long n = pix / P.hw, rem = pix % P.hw;
+            const float o[3] = {s0, s1, s2}, dd[3] = {d0, d1, d2};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float out = ni[P.alb_spec_ch + c] * (o[c] / (float)P.n_spec);
+                if (P.n_diff > 0) out = out + ni[P.alb_diff_ch + c] * (dd[c] / (float)P.n_diff);
+                P.image[(n * 3 + c) * P.hw + rem] = out;
+            }
+        }
     }
 }
 
@@ -768,7 +830,7 @@ extern "C" int rnr_ray_render(const float* unet_raw, int c_out_pad, const float*
     P.alpha = alpha; P.lp = lp; P.lp_h = lp_h; P.lp_w = lp_w; P.n_spec = num_spec; P.n_diff = num_diff;
     P.alb_diff_ch = albedo_diff_ch; P.alb_spec_ch = albedo_spec_ch; P.image = image;
     P.npix = (long)num_views * height * width; P.hw = height * width;
-    const long lanes = P.npix * 32;
+    const long lanes = (P.npix + RR_PIX - 1) / RR_PIX * 32;
     hipLaunchKernelGGL(ray_render_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, as_stream(stream), P);
     return check_launch("ray_render_kernel");
 }
