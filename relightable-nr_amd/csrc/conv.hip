@@ -20,6 +20,7 @@
 namespace rnr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr int CTHREADS = 256;
@@ -350,11 +351,14 @@ conv_mfma_kernel(const ConvParams P) {
 // Pipeline step = one (chunk, tap): the next step's weights and a slice of the next chunk's halo are fetched to
 // registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4) ? 3 : (KIND == 1 && WM * WN <= 4 ? 2 : 1))
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
+__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? 3 : (WM * WN <= 4 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
     constexpr int TW = 32, TH = WAVES_M * WM;
-    constexpr int BN = WAVES_N * WN * 32;
+    // R16 = 1 adds a 16-column remainder tile per wave on v_mfma_f32_16x16x4_f32 (same FLOP rate): Cout = 78 runs as
+    // 64 + 16 = 80 columns instead of 96.
+    constexpr int WCOLS = WN * 32 + R16 * 16;
+    constexpr int BN = WAVES_N * WCOLS;
     constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
     constexpr int HWD = KIND == 1 ? 2 * TW + 2 : TW + 2;   // halo width  34 / 66
     constexpr int HHT = KIND == 1 ? 2 * TH + 2 : TH + 2;   // halo height
@@ -381,7 +385,8 @@ conv_halo_kernel(const ConvParams P) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int wn0 = wave_n * WN * 32;
+    const int wn0 = wave_n * WCOLS;
+    const int l15 = lane & 15, kq = lane >> 4;
     int mt_, nt_, z_;
     tile_coords(P, mt_, nt_, z_);
     const int par = (KIND == 2) ? (z_ & 3) : 0;
@@ -488,6 +493,10 @@ conv_halo_kernel(const ConvParams P) {
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
+    floatx4 acc16[R16 ? 2 * WM : 1];
+#pragma unroll
+    for (int i = 0; i < (R16 ? 2 * WM : 1); i++) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
 #pragma unroll
@@ -545,6 +554,20 @@ conv_halo_kernel(const ConvParams P) {
                     for (int j = 0; j < WN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+            if (R16) {      // 16-column remainder: A[row = l&15][k = l>>4], B[k = l>>4][col = l&15], four k per instruction
+                const float* a16 = As + abuf * (BK * LDA) + aoff + l15;
+                const float* b16 = Bs + (step & 1) * (BK * LDB) + wn0 + WN * 32 + l15;
+#pragma unroll
+                for (int s4 = 0; s4 < BK / 4; s4++) {
+                    const int k = 4 * s4 + kq;
+                    const float bv = b16[k * LDB];
+#pragma unroll
+                    for (int sb = 0; sb < 2 * WM; sb++) {
+                        const float av16 = a16[k * LDA + (sb >> 1) * ROWSTEP + (sb & 1) * 16];
+                        acc16[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av16, bv, acc16[sb], 0, 0, 0);
+                    }
+                }
+            }
             if (ABUFS == 2) {
 #pragma unroll
                 for (int u = 0; u < APS; u++) {
@@ -580,6 +603,21 @@ conv_halo_kernel(const ConvParams P) {
             }
         }
     }
+    if (R16) {   // C layout of the 16x16 tiles: col = lane & 15, row = (lane >> 4) * 4 + reg
+        const int col = n0 + wn0 + WN * 32 + l15;
+#pragma unroll
+        for (int sb = 0; sb < 2 * WM; sb++) {
+            const int y = y0 + wave_m * WM + (sb >> 1);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int x = x0 + (sb & 1) * 16 + kq * 4 + g;
+                const size_t off = (KIND == 2)
+                    ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
+                    : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
+                if (col < P.c_out_pad) out[off + col] = acc16[sb][g];
+            }
+        }
+    }
     if (P.stats && P.splitk == 1) {
         float* red = As;   // [WAVES_M][BN][2]; LDS is free after the last barrier
 #pragma unroll
@@ -597,6 +635,24 @@ conv_halo_kernel(const ConvParams P) {
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) {
                 const int col = wn0 + 32 * j + l31;
+                red[(wave_m * BN + col) * 2 + 0] = s1;
+                red[(wave_m * BN + col) * 2 + 1] = s2;
+            }
+        }
+        if (R16) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 2 * WM; sb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float v = acc16[sb][g];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (kq == 0) {
+                const int col = wn0 + WN * 32 + l15;
                 red[(wave_m * BN + col) * 2 + 0] = s1;
                 red[(wave_m * BN + col) * 2 + 1] = s2;
             }
@@ -619,18 +675,18 @@ conv_halo_kernel(const ConvParams P) {
     }
 }
 
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
-    constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32;
+    constexpr int TH = WAVES_M * WM, BN = WAVES_N * (WN * 32 + R16 * 16);
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
     constexpr size_t lds = (size_t)((KIND == 1 ? 1 : 2) * BK * HP + 2 * BK * (BN + 4)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {    // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
+    hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>), grid, dim3(CTHREADS), lds, st, P);
 }
 
 // out[m,c] = sum_s slab[s][m,c]; statistics per view.  grid (rows/64, c_out_pad/64), 256 threads.
@@ -741,8 +797,9 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     p->M = N * p->Ho * p->Wo;
     p->chunks_per_tap = (d->c_in0_pad + d->c_in1_pad) / BK;
     p->kt_total = p->taps * p->chunks_per_tap;
+    // cfg 1: 256 x 96 columns in the gather kernel, 256 x 80 (64 + a 16-column remainder tile) in the halo kernel
     if (d->c_out_pad <= 64) { p->cfg = 0; p->bm = 256; p->bn = 64; }
-    else if (d->c_out_pad <= 96) { p->cfg = 1; p->bm = 256; p->bn = 96; }
+    else if (d->c_out_pad <= 80) { p->cfg = 1; p->bm = 256; p->bn = 96; }
     else { p->cfg = 2; p->bm = 128; p->bn = 128; }
     p->mtiles = (p->M + p->bm - 1) / p->bm;
     p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
@@ -755,7 +812,10 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     }
     const int th = p->bm / 32;
     p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
-    if (p->halo) p->mtiles = N * (p->Ho / th) * (p->Wo / 32);
+    if (p->halo) {
+        p->mtiles = N * (p->Ho / th) * (p->Wo / 32);
+        if (p->cfg == 1) { p->bn = 80; p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn; }
+    }
     const long tiles = (long)p->mtiles * p->ntiles * p->par;
     int sk = 1;
     if (tiles < 256) {
@@ -774,9 +834,9 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
 template <int KIND>
 static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
     const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
-    if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2>(grid, P, st);
-    else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 3>(grid, P, st);
-    else launch_halo_cfg<KIND, 2, 2, 2, 2>(grid, P, st);
+    if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
+    else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 2, 1>(grid, P, st);      // 256 x 80
+    else launch_halo_cfg<KIND, 2, 2, 2, 2, 0>(grid, P, st);
 }
 
 template <int KIND>
