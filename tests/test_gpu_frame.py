@@ -53,3 +53,64 @@ def test_frame256_vs_oracle():
     assert mism < 1e-3, mism
     p = orc.psnr(img, ref['image'])
     assert p > 55.0, p
+
+
+def test_frame1024_c16_vs_oracle():
+    """BASELINE config 5 shape class: 1024x1024, 16-channel neural texture (U-Net input 78 + 6 + 16 = 100 -> 78),
+    lighting from a 4096-sample SH projection of an environment map (lmax 10).  Small nf0 keeps the CPU oracle fast."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import lighting, scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    S = 1024
+    sc = testing.tiny_scene(img_size=S, nf0=8, tex_size=256, tex_ch=16, nlat=24, nlon=48, seed=2)
+    env = testing.synthetic_light_probe(160, 320, 7)[0]
+    l_dir = T(scene.sphere_samples(4096)).t().contiguous()
+    coeff, _, _ = lighting.envmap_to_sh(env.to(DEV), l_dir.to(DEV), 10)
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=8,
+                       max_views=1, device=DEV, sh_coeff=coeff[None], sh_lmax=10)
+    views = {k: T(v) for k, v in scene.spiral_views(S, [77]).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    img = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True).cpu()
+    assert pipe.unet.in_c_pad == 112 and pipe.c_in == 100
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    lp = orc.reconstruct_lp(coeff.cpu(), basis)[None]
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    ref = orc.render_frame(mesh_t, views, S, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'], sc['pivots_diff'])
+    assert (pipe.last['gb']['face_index_map'].cpu() != ref['face_index_map']).float().mean() < 1e-3
+    p = orc.psnr(img, ref['image'])
+    assert p > 55.0, p
+
+
+def test_all_background_view():
+    """Camera looking away from the mesh: every pixel is background (face index -1 wraps to the last face with zero
+    weights, uv = (0,0), rays_uv = -1, network.py:176-190, 469-470).  The frame must still match the oracle."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    sc = testing.tiny_scene(img_size=64, nf0=4, tex_size=32, tex_ch=16, nlat=8, nlon=16, seed=4)
+    pipe = RNRPipeline(sc['mesh'], 64, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], sc['lp'], nf0=4,
+                       max_views=2, device=DEV)
+    v = scene.spiral_views(64, [10, 20])
+    away = scene.rt_from_pos_lookat(np.array([0.0, 0.0, 3.0]), cam_lookat=(0.0, 0.0, 9.0)).astype(np.float32)
+    v['pose'][1] = away
+    v['R_inv'][1] = away[:3, :3].T
+    views = {k: T(x) for k, x in v.items()}
+    dv = {k: x.to(DEV) for k, x in views.items()}
+    img = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True).cpu()
+    assert int((pipe.last['gb']['face_index_map'][1] >= 0).sum()) == 0
+    assert torch.isfinite(img).all()
+    mesh_t = {k: torch.as_tensor(x) for k, x in sc['mesh'].items()}
+    ref = orc.render_frame(mesh_t, views, 64, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'], sc['pivots_diff'])
+    assert orc.psnr(img, ref['image']) > 60.0
+
+
+def test_bad_arguments_raise():
+    from rnr_amd import _lib, ops
+    with pytest.raises(RuntimeError):
+        ops.sh_basis(torch.zeros(4, 3, device=DEV), 40)                       # lmax out of range
+    with pytest.raises(RuntimeError):
+        ops.project_vertices(torch.zeros(4, 3, device=DEV), torch.zeros(1, 3, 3, device=DEV).double(),
+                             torch.zeros(1, 3, 3, device=DEV), torch.zeros(1, 3, device=DEV), 64)    # wrong dtype
+    with pytest.raises(RuntimeError):
+        ops.nchw_to_nhwc(torch.zeros(1, 8, 4, 4, device=DEV), 4)              # c_pad < c
+    assert isinstance(_lib.load().rnr_last_error(), bytes)
