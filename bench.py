@@ -128,18 +128,28 @@ def main():
     ids = (np.arange(n_total) * 7) % 720
     allv = scene.spiral_views(args.img_size, ids)
     poses = {k: torch.from_numpy(v).to(dev) for k, v in allv.items()}
-    gathered = torch.empty(world * V, 3, args.img_size, args.img_size, device=dev) if world > 1 else None
+    gathered = [torch.empty(world * V, 3, args.img_size, args.img_size, device=dev) for _ in range(2)] if world > 1 else None
+    pending = []
 
     def step(s):
         lo = (s * world + rank) * V
         sl = slice(lo, lo + V)
         img = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
         if world > 1:
-            dist.all_gather_into_tensor(gathered, img)       # frames over xGMI; the only exchange of the path
+            # frames over xGMI — the only exchange of the path.  Issued asynchronously (RCCL's own stream) so that the
+            # gather of step s overlaps the rendering of step s+1; frame / gather buffers are double-buffered.
+            pending.append(dist.all_gather_into_tensor(gathered[s & 1], img, async_op=True))
+            if len(pending) > 1:
+                pending.pop(0).wait()
         return img
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()
 
     for s in range(args.warmup):
         step(s)
+    drain()
     # ---- per-stage HIP-event timing of the dominant stage (U-Net convs) on the launch stream ----
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
     orig_forward = pipe.unet.forward
@@ -157,6 +167,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
         img = step(s)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

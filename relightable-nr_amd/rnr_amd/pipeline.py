@@ -61,7 +61,9 @@ class RNRPipeline:
         self._gb = {}
         self._gb_maps = ['face_index_map', 'alpha', 'uv_map', 'normal_map']
         self._net_in = torch.empty(N, S, S, self.unet.in_c_pad, dtype=torch.float32, device=self.dev)
-        self._image = torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev)
+        # two frame buffers: a caller that overlaps the all-gather of step k with the rendering of step k+1 alternates
+        self._images = [torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self._flip = 0
         self._ws = torch.empty(ops._lib.load().rnr_gbuffer_workspace_bytes(N, self.mesh.num_faces, S), dtype=torch.uint8,
                                device=self.dev)
         for m in self._gb_maps:
@@ -74,7 +76,8 @@ class RNRPipeline:
         self.lp = lp.reshape(lp.shape[-3], lp.shape[-2], 3).contiguous().to(self.dev)
 
     def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False, lighting_idx=0):
-        """proj/proj_inv/R_inv [N,3,3], pose [N,4,4] device float32 -> image [N,3,S,S] (a view into a reused buffer)."""
+        """proj/proj_inv/R_inv [N,3,3], pose [N,4,4] device float32 -> image [N,3,S,S].  The result is a view into one of
+        two internal buffers used alternately: it stays valid until the call after next."""
         N = proj.shape[0]
         if N > self.max_views:
             raise RuntimeError('pipeline built for max_views=%d, got %d poses' % (self.max_views, N))
@@ -92,7 +95,8 @@ class RNRPipeline:
                               net_in=self._net_in[:N])
         raw = self.unet.forward(sh['net_in'], N)
         img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff,
-                             albedo_diff_ch=0, albedo_spec_ch=3, image=self._image[:N])
+                             albedo_diff_ch=0, albedo_spec_ch=3, image=self._images[self._flip][:N])
+        self._flip ^= 1
         if keep_intermediates:
             self.last = {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}
         return img

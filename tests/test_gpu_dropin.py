@@ -159,3 +159,50 @@ def test_neural_renderer_api_on_gpu(golden):
     out = nr.rasterize_rgbad(faces, tex, 64, anti_aliasing=True, near=0.0, far=1e5, eps=1e-3)
     assert out['rgb'].shape == (2, 3, 64, 64) and out['alpha'].shape == (2, 64, 64)
     assert float(out['rgb'].abs().max()) == 0.0
+
+
+def test_dnr_view_with_dropin_modules():
+    """BASELINE config 1 (test_dnr.py:166-217): texture_mapper(uv, sh) [sh_start_ch=3] -> RenderingNet(30 -> 3, nf0 = 80,
+    use_gcn=False) -> (y*0.5+0.5)*2 * alpha, one 256x256 view, real DNR sizes (train_dnr.py:29-38)."""
+    import network
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops, scene, testing
+    S, C, nf0 = 256, 30, 80
+    mesh = scene.uv_sphere(32, 64)
+    dm = ops.DeviceMesh(mesh['v'], mesh['vt'], mesh['vn'], mesh['f_v_idx'], mesh['f_vt_idx'], mesh['f_vn_idx'], DEV)
+    v = {k: T(x) for k, x in scene.spiral_views(S, [33]).items()}
+    proj, pose = v['proj'].to(DEV), v['pose'].to(DEV)
+    v_uvz = ops.project_vertices(dm.v, proj, pose[:, :3, :3].contiguous(), pose[:, :3, 3].contiguous(), S)
+    gb = ops.rasterize_gbuffer(dm, v_uvz, pose, S)
+    import camera
+    import sph_harm
+    vd, _ = camera.get_view_dir_map((S, S), v['proj_inv'].to(DEV), v['R_inv'].to(DEV))
+    sh = torch.from_numpy(sph_harm.evaluate_sh_basis(lmax=2, directions=vd.reshape(-1, 3).cpu().numpy())
+                          .reshape(1, S, S, 9).astype(np.float32)).to(DEV)
+    tm = network.TextureMapper(512, C, 4, apply_sh=True)
+    tex = testing.synthetic_textures(512, C, 4, 5)
+    tsd = tm.state_dict()
+    for i in range(4):
+        tsd['textures.%d' % i] = tex[i]
+    tm.load_state_dict(tsd, strict=True)
+    net = network.RenderingNet(nf0=nf0, in_channels=C, out_channels=3, num_down_unet=5, use_gcn=False)
+    sd = testing.unet_state_dict(C, 3, nf0, seed=5, use_gcn=False)
+    full = net.state_dict()
+    for k, val in sd.items():
+        full[k[4:] if not k.startswith('net.') else k] = val
+    net.load_state_dict(full, strict=True)      # aliases (in_layer.0.weight ...) are tied to the same Parameters
+    tm.to(DEV).eval()
+    net.to(DEV).eval()
+    for m in net.modules():
+        if type(m) == torch.nn.BatchNorm2d:
+            m.train()
+    with torch.no_grad():
+        neural_img = tm(gb['uv_map'], sh)                               # default sh_start_ch = 3 (test_dnr.py:210)
+        y = net(neural_img, None)
+        out = (y * 0.5 + 0.5) * 2.0 * gb['alpha'][:, None]
+    ref_neural = orc.texture_mapper([t for t in tex], gb['uv_map'].cpu(), sh.cpu(), 3)
+    assert torch.allclose(neural_img.cpu(), ref_neural, atol=2e-5)
+    ref_y = orc.unet_forward(sd, ref_neural)
+    ref = (ref_y * 0.5 + 0.5) * 2.0 * gb['alpha'].cpu()[:, None]
+    assert out.shape == (1, 3, S, S)
+    assert orc.psnr(out.cpu(), ref, peak=2.0) > 60.0
