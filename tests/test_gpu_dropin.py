@@ -1,6 +1,8 @@
 """-m gpu: the reference's per-view loop (test_rnr.py:265-377) written against the DROP-IN modules
 (`network`, `render`, `camera`, `sph_harm`, `neural_renderer`), compared with the golden vectors the reference's own
 modules produced.  This is the "a user switches the import path and nothing else" check."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -206,3 +208,33 @@ def test_dnr_view_with_dropin_modules():
     ref = (ref_y * 0.5 + 0.5) * 2.0 * gb['alpha'].cpu()[:, None]
     assert out.shape == (1, 3, S, S)
     assert orc.psnr(out.cpu(), ref, peak=2.0) > 60.0
+
+
+def test_precompute_export(golden, tmp_path):
+    """G-buffer export (.mat, precompute.py's directory layout / keys) from the HIP rasterizer, read back and compared
+    with the reference-generated maps of the rasterizer_module64 fixture."""
+    import scipy.io
+    import network
+    from rnr_amd import precompute, scene
+    gm = golden('rasterizer_module64')
+    obj = str(tmp_path / 'sphere.obj')
+    scene.write_obj(obj, {k: gm['mesh_' + k] for k in ['v', 'vt', 'vn', 'f_v_idx', 'f_vt_idx', 'f_vn_idx']})
+    ras = network.Rasterizer(obj_fp=obj, img_size=64, global_RT=T(gm['global_RT'])).to(DEV)
+    view = {k: T(gm[k][:1]) for k in ['proj', 'pose', 'proj_inv', 'R_inv']}
+    out = str(tmp_path / 'precomp')
+    precompute.export_view_maps(ras, view, out, '00000')
+    r = scipy.io.loadmat(out + '/raster/00000.mat')
+    assert set(['face_index_map', 'weight_map', 'faces_v_idx', 'v_uvz', 'v_front_mask']) <= set(r.keys())
+    mism = r['face_index_map'] != gm['view0_face_index_map'][0]
+    assert mism.mean() < 2e-3
+    uv = scipy.io.loadmat(out + '/uv_map/00000.mat')['uv_map']
+    d = np.abs(uv - gm['view0_uv_map'][0])[~mism]
+    assert np.minimum(d, 1 - d).max() < 1e-4
+    nm = scipy.io.loadmat(out + '/normal_map/00000.mat')['normal_map']
+    assert np.abs(nm - gm['view0_normal_map'][0])[~mism].max() < 1e-4
+    for sub in ['TBN_map', 'pose', 'proj', 'normal_map_cam', 'position_map', 'position_map_cam', 'view_dir_map',
+                'view_dir_map_cam', 'view_dir_map_tangent', 'sh_basis_map', 'reflect_dir_map']:
+        assert os.path.isfile('%s/%s/00000.mat' % (out, sub)), sub
+    gs = golden('shading_geometry64')
+    vd = scipy.io.loadmat(out + '/view_dir_map/00000.mat')['view_dir_map']
+    assert np.abs(vd - gs['view_dir'][0]).max() < 2e-6
