@@ -39,6 +39,7 @@ struct ConvParams {
     int OH, OW;         // true output size
     int M;              // GEMM rows (per parity class)
     int c_out, c_out_pad;
+    int wstride;        // floats per packed weight row: c_out_pad rounded up to 128 (tiles never read past a row)
     int chunks0, chunks_per_tap, kt_total;
     int splitk;
     long slab_stride;   // floats between split-K slabs
@@ -182,7 +183,7 @@ conv_mfma_kernel(const ConvParams P) {
             if (idx < BQ) {
                 const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
                 const int col = n0 + 4 * c4;
-                if (col < P.c_out_pad) w = *reinterpret_cast<const float4*>(P.weight + (krow0 + kr) * P.c_out_pad + col);
+                if (col < P.c_out_pad) w = *reinterpret_cast<const float4*>(P.weight + (krow0 + kr) * P.wstride + col);
             }
             breg[b] = w;
         }
@@ -371,9 +372,10 @@ conv_halo_kernel(const ConvParams P) {
     // profiles/r01_pmc_per_kernel_v4): keep ONE LDS copy, carry the next chunk's halo in registers across the 16 taps
     // and swap it in between chunks (one extra barrier per chunk) -> two workgroups per CU.
     constexpr int ABUFS = KIND == 1 ? 1 : 2;
-    constexpr int LDB = BN + 4;
+    constexpr int LDB = BN;                                // unpadded: the weight tile is DMA'd (global_load_lds) linearly
     constexpr int BQ = BK * BN / 4;
     constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
+    static_assert(BQ % 64 == 0, "whole waves per DMA pass");
     static_assert(LDA % 8 == 4, "LDA chosen for <= 2-way ds_write bank conflicts");
     static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
 
@@ -459,28 +461,23 @@ conv_halo_kernel(const ConvParams P) {
             }
         }
     };
-    float4 breg[BPT];
-    auto load_b = [&](int c, int t) {
+    // Weight tile of one (chunk, tap): BK rows x BN floats, contiguous per row in the packed layout (row stride
+    // P.wstride >= ntiles*BN, so no column masking).  It goes global -> LDS by DMA (global_load_lds_dwordx4: no VGPRs,
+    // no ds_write; LDS image = wave-uniform base + lane*16 B, i.e. exactly the linear [BK][BN] tile).  The barrier
+    // that ends the step drains it (hipcc emits vmcnt(0) before s_barrier while an LDS-DMA is in flight).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_b = [&](int c, int t, int buf) {
         const size_t krow0 = ((size_t)(par * TAPS + t) * nchunks + c) * BK;
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
-            const int idx = tid + CTHREADS * b;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BQ) {
+            const int idx0 = wave_u * 64 + CTHREADS * b;           // first slot of this wave in pass b (wave-uniform)
+            if (idx0 < BQ) {
+                const int idx = idx0 + lane;
                 const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
-                const int col = n0 + 4 * c4;
-                if (col < P.c_out_pad) w = *reinterpret_cast<const float4*>(P.weight + (krow0 + kr) * P.c_out_pad + col);
-            }
-            breg[b] = w;
-        }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int b = 0; b < BPT; b++) {
-            const int idx = tid + CTHREADS * b;
-            if (idx < BQ) {
-                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
-                *reinterpret_cast<float4*>(Bs + buf * (BK * LDB) + kr * LDB + 4 * c4) = breg[b];
+                const float* g = P.weight + (krow0 + kr) * P.wstride + n0 + 4 * c4;
+                float* l = Bs + buf * (BK * LDB) + idx0 * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)l, 16, 0, 0);
             }
         }
     };
@@ -501,8 +498,7 @@ conv_halo_kernel(const ConvParams P) {
         const ChunkSrc cs = chunk_src(c_begin);
 #pragma unroll
         for (int j = 0; j < APT; j++) store_a(cs, load_a(cs, j), j, 0);
-        load_b(c_begin, 0);
-        store_b(0);
+        dma_b(c_begin, 0, 0);
     }
     __syncthreads();
     int step = 0;
@@ -514,18 +510,22 @@ conv_halo_kernel(const ConvParams P) {
 #pragma unroll
         for (int t = 0; t < TAPS; t++, step++) {
             const bool more = next_chunk || t < TAPS - 1;
+#ifndef RNR_ABLATE_NOLOAD
             if (more) {
-                if (t < TAPS - 1) load_b(c, t + 1); else load_b(c + 1, 0);
+                if (t < TAPS - 1) dma_b(c, t + 1, (step + 1) & 1); else dma_b(c + 1, 0, (step + 1) & 1);
             }
+#endif
             float4 av[APS];
 #pragma unroll
             for (int u = 0; u < APS; u++) {
                 const int j = t * APS + u;
                 av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef RNR_ABLATE_NOLOAD
                 if (next_chunk && j < APT) {
                     av[u] = load_a(csn, j);
                     if (ABUFS == 1) av_all[j] = av[u];
                 }
+#endif
             }
             // LDS element of output row (wave_m*WM + i), lane x for this tap
             int aoff;
@@ -568,6 +568,7 @@ conv_halo_kernel(const ConvParams P) {
                     }
                 }
             }
+#ifndef RNR_ABLATE_NOLOAD
             if (ABUFS == 2) {
 #pragma unroll
                 for (int u = 0; u < APS; u++) {
@@ -575,8 +576,10 @@ conv_halo_kernel(const ConvParams P) {
                     if (next_chunk && j < APT) store_a(csn, av[u], j, abuf ^ 1);
                 }
             }
-            if (more) store_b((step + 1) & 1);
+#endif
+#ifndef RNR_ABLATE_NOBARRIER
             __syncthreads();
+#endif
         }
         if (ABUFS == 1 && next_chunk) {     // every wave is past the last tap's reads: swap the next halo in
 #pragma unroll
@@ -679,7 +682,7 @@ template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM, BN = WAVES_N * (WN * 32 + R16 * 16);
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds = (size_t)((KIND == 1 ? 1 : 2) * BK * HP + 2 * BK * (BN + 4)) * sizeof(float);
+    constexpr size_t lds = (size_t)((KIND == 1 ? 1 : 2) * BK * HP + 2 * BK * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {    // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>),
@@ -748,14 +751,17 @@ bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ g
     shift[i] = sh;
 }
 
+__host__ __device__ __forceinline__ int weight_row_stride(int c_out_pad) { return (c_out_pad + 127) / 128 * 128; }
+
 __global__ void __launch_bounds__(256)
 pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restrict__ packed, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int taps = d.kind == RNR_CONV3x3_REFLECT ? 9 : (d.kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
     const int ctot = d.c_in0_pad + d.c_in1_pad;
-    const int co = (int)(i % d.c_out_pad);
-    long r = i / d.c_out_pad;
+    const int wstride = weight_row_stride(d.c_out_pad);
+    const int co = (int)(i % wstride);
+    long r = i / wstride;
     const int c = (int)(r % ctot);
     r /= ctot;
     const int tp = (int)(r % taps);
@@ -866,7 +872,7 @@ using namespace rnr;
 extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
     if (!d) return 0;
     const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : (d->kind == RNR_CONV4x4S2_REFLECT ? 16 : 16);
-    return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)d->c_out_pad;
+    return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
 }
 
 extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream) {
@@ -912,7 +918,7 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
     }
     P.weight = weight_packed; P.stats = stats;
     P.N = num_views; P.H = in_h; P.W = in_w; P.Ho = pl.Ho; P.Wo = pl.Wo; P.OH = pl.OH; P.OW = pl.OW; P.M = pl.M;
-    P.c_out = d->c_out; P.c_out_pad = d->c_out_pad;
+    P.c_out = d->c_out; P.c_out_pad = d->c_out_pad; P.wstride = weight_row_stride(d->c_out_pad);
     P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
     P.splitk = pl.splitk;
     P.mtiles = pl.mtiles; P.ntiles = pl.ntiles; P.zdim = pl.splitk * pl.par;
