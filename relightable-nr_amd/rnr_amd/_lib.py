@@ -92,11 +92,27 @@ class RnrError(RuntimeError):
     pass
 
 
+def _build_from_source():
+    """A source checkout without the built library: compile it with hipcc if the ROCm toolchain is there (still the
+    HIP path — there is nothing else to fall back to).  Errors surface in load()."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or ('/opt/rocm/bin/hipcc' if os.path.isfile('/opt/rocm/bin/hipcc') else None)
+    if hipcc is None:
+        return
+    try:
+        subprocess.check_call(['make', '-C', os.path.join(os.path.dirname(_HERE), 'csrc'), '-s', '-j4', 'HIPCC=' + hipcc])
+    except (subprocess.CalledProcessError, OSError):
+        pass
+
+
 def load():
     """Load librnr_hip.so (does not need a GPU; launching kernels does)."""
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.isfile(LIB_PATH):
+        _build_from_source()
     if not os.path.isfile(LIB_PATH):
         raise RnrError('librnr_hip.so not found at %s - build it first: `python -c "import __graft_entry__ as g; '
                        'g.build()"` or `make -C relightable-nr_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
