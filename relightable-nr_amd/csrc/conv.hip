@@ -24,6 +24,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr int CTHREADS = 256;
+#ifndef RNR_HALO_WAVES
+#define RNR_HALO_WAVES 3    // waves per SIMD the halo kernels are register-bounded for (4 would spill and exceed LDS anyway)
+#endif
 
 struct ConvParams {
     const float* src_data[2];
@@ -353,7 +356,7 @@ conv_mfma_kernel(const ConvParams P) {
 // registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
-__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? 3 : (WM * WN <= 4 ? 2 : 1))
+__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 4 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
     constexpr int TW = 32, TH = WAVES_M * WM;
     // R16 = 1 adds a 16-column remainder tile per wave on v_mfma_f32_16x16x4_f32 (same FLOP rate): Cout = 78 runs as
