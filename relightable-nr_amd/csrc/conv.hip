@@ -580,7 +580,10 @@ conv_halo_kernel(const ConvParams P) {
                 }
             }
 #endif
-#ifndef RNR_ABLATE_NOBARRIER
+#ifdef RNR_ABLATE_RAWBAR
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#elif !defined(RNR_ABLATE_NOBARRIER)
             __syncthreads();
 #endif
         }
@@ -695,42 +698,57 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
     hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>), grid, dim3(CTHREADS), lds, st, P);
 }
 
-// out[m,c] = sum_s slab[s][m,c]; statistics per view.  grid (rows/64, c_out_pad/64), 256 threads.
+// out[m,c] = sum_s slab[s][m,c]; statistics per view.  One float4 of one output row per thread (16 rows x 64 columns
+// per 256-thread workgroup), so even the 16x16 maps spread over >= 128 workgroups.
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk, float* __restrict__ out,
                      double* __restrict__ stats, long rows, int rows_per_view, int c_out, int c_out_pad) {
-    __shared__ float red[4][64][2];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = blockIdx.y * 64 + cx;
-    const long r0 = (long)blockIdx.x * 64;
-    const bool single_view = (r0 / rows_per_view) == ((min(r0 + 64, rows) - 1) / rows_per_view);
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = ry; r < 64; r += 4) {
-        const long m = r0 + r;
-        if (m < rows && col < c_out_pad) {
-            float v = 0.f;
-            for (int s = 0; s < splitk; s++) v += slabs[(size_t)s * slab_stride + (size_t)m * c_out_pad + col];
-            out[(size_t)m * c_out_pad + col] = v;
-            if (stats && col < c_out) {
-                if (single_view) { s1 += v; s2 += v * v; }
-                else {
-                    double* st = stats + ((size_t)(m / rows_per_view) * c_out_pad + col) * 2;
-                    atomicAdd(st + 0, (double)v);
-                    atomicAdd(st + 1, (double)v * (double)v);
-                }
-            }
+    __shared__ float red[16][64][2];
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int col = blockIdx.y * 64 + cq * 4;
+    const long r0 = (long)blockIdx.x * 16;
+    const long m = r0 + ry;
+    const bool single_view = (r0 / rows_per_view) == ((min(r0 + 16, rows) - 1) / rows_per_view);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = m < rows && col < c_out_pad;
+    if (live) {
+        const float* p = slabs + (size_t)m * c_out_pad + col;
+        for (int s = 0; s < splitk; s++) {
+            const float4 t = *reinterpret_cast<const float4*>(p + (size_t)s * slab_stride);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
+        *reinterpret_cast<float4*>(out + (size_t)m * c_out_pad + col) = v;
     }
     if (!stats) return;
-    red[ry][cx][0] = s1;
-    red[ry][cx][1] = s2;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (!single_view) {     // rows of two views in one workgroup: maps smaller than 16 pixels
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (col + k < c_out) {
+                    double* st = stats + ((size_t)(m / rows_per_view) * c_out_pad + col + k) * 2;
+                    atomicAdd(st + 0, (double)vv[k]);
+                    atomicAdd(st + 1, (double)vv[k] * (double)vv[k]);
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        red[ry][cq * 4 + k][0] = live ? vv[k] : 0.f;
+        red[ry][cq * 4 + k][1] = live ? vv[k] * vv[k] : 0.f;
+    }
     __syncthreads();
-    if (single_view && ry == 0 && col < c_out) {
-        const double a = (double)red[0][cx][0] + (double)red[1][cx][0] + (double)red[2][cx][0] + (double)red[3][cx][0];
-        const double b = (double)red[0][cx][1] + (double)red[1][cx][1] + (double)red[2][cx][1] + (double)red[3][cx][1];
-        double* st = stats + ((size_t)(r0 / rows_per_view) * c_out_pad + col) * 2;
-        atomicAdd(st + 0, a);
-        atomicAdd(st + 1, b);
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.y * 64 + threadIdx.x;
+        if (c < c_out) {
+            double a = 0.0, b2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { a += (double)red[r][threadIdx.x][0]; b2 += (double)red[r][threadIdx.x][1]; }
+            double* st = stats + ((size_t)(r0 / rows_per_view) * c_out_pad + c) * 2;
+            atomicAdd(st + 0, a);
+            atomicAdd(st + 1, b2);
+        }
     }
 }
 
@@ -946,7 +964,7 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
     if (int e = check_launch("conv_mfma_kernel")) return e;
     if (pl.splitk > 1) {
         const long rows = (long)num_views * pl.OH * pl.OW;
-        const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((d->c_out_pad + 63) / 64));
+        const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)((d->c_out_pad + 63) / 64));
         hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, reinterpret_cast<const float*>(workspace),
                            (long)out_floats, pl.splitk, out_raw, stats, rows, pl.OH * pl.OW, d->c_out, d->c_out_pad);
         if (int e = check_launch("splitk_reduce_kernel")) return e;

@@ -503,15 +503,26 @@ sh_basis_kernel(const float* __restrict__ dirs, float* __restrict__ out, int n, 
     }
 }
 
+// out[s,c] = sum_b basis[s,b] * coeff[b,c].  64 samples per workgroup: their basis rows are one contiguous block of
+// 64*nb floats, staged through LDS with coalesced loads (a lane-per-output version reads rows nb floats apart).
+constexpr int SHR_ROWS = 64;
 __global__ void __launch_bounds__(256)
 sh_reconstruct_kernel(const float* __restrict__ basis, const float* __restrict__ coeff, float* __restrict__ out,
                       int ns, int nb, int nc) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)ns * nc) return;
-    const int s = (int)(i / nc), c = (int)(i % nc);
-    float acc = 0.f;
-    for (int b = 0; b < nb; b++) acc += basis[(size_t)s * nb + b] * coeff[b * nc + c];
-    out[i] = acc;
+    extern __shared__ float sh_lds[];              // [SHR_ROWS*nb] basis rows, then [nb*nc] coefficients
+    float* bl = sh_lds;
+    float* cl = sh_lds + SHR_ROWS * nb;
+    const int s0 = blockIdx.x * SHR_ROWS;
+    const int rows = min(SHR_ROWS, ns - s0);
+    for (int i = threadIdx.x; i < rows * nb; i += blockDim.x) bl[i] = basis[(size_t)s0 * nb + i];
+    for (int i = threadIdx.x; i < nb * nc; i += blockDim.x) cl[i] = coeff[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < rows * nc; o += blockDim.x) {
+        const int s = o / nc, c = o - s * nc;
+        float acc = 0.f;
+        for (int b = 0; b < nb; b++) acc += bl[s * nb + b] * cl[b * nc + c];
+        out[(size_t)(s0 + s) * nc + c] = acc;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -846,8 +857,9 @@ extern "C" int rnr_sh_reconstruct(const float* basis, const float* coeff, float*
                                   int num_basis, int num_channels, void* stream) {
     RNR_REQUIRE(basis && coeff && out && num_samples > 0 && num_basis > 0 && num_channels > 0,
                 "rnr_sh_reconstruct: bad arguments");
-    const long total = (long)num_samples * num_channels;
-    hipLaunchKernelGGL(sh_reconstruct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    const size_t lds = (size_t)(SHR_ROWS * num_basis + num_basis * num_channels) * sizeof(float);
+    RNR_REQUIRE(lds <= 64 * 1024, "rnr_sh_reconstruct: num_basis * (64 + num_channels) floats must fit 64 KiB of LDS");
+    hipLaunchKernelGGL(sh_reconstruct_kernel, dim3((unsigned)((num_samples + SHR_ROWS - 1) / SHR_ROWS)), dim3(256), lds,
                        as_stream(stream), basis, coeff, out, num_samples, num_basis, num_channels);
     return check_launch("sh_reconstruct_kernel");
 }
