@@ -202,6 +202,19 @@ def main():
                          'traffic_source': traffic_src,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms},
         }
+        if world == 1 and V > 1:
+            # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
+            # (same pipeline, 1 pose per step; outside the timed region above)
+            for s in range(3):
+                pipe.render(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1], poses['R_inv'][s:s + 1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n1 = 40
+            for s in range(n1):
+                pipe.render(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1], poses['R_inv'][s:s + 1])
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / n1
+            res['single_view_mode'] = {'views_per_step': 1, 'ms_per_frame': dt1 * 1e3, 'frames_per_s': 1.0 / dt1}
         if not args.no_cpu_baseline and world == 1:
             last_id = int(ids[(args.warmup + args.steps - 1) * V + V - 1])
             hip_last = None if args.no_parity else img[V - 1:V]

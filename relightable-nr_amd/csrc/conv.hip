@@ -24,6 +24,10 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr int CTHREADS = 256;
+#ifndef RNR_SPLITK_BELOW
+#define RNR_SPLITK_BELOW 256
+#define RNR_SPLITK_TARGET 512
+#endif
 #ifndef RNR_HALO_WAVES
 #define RNR_HALO_WAVES 3    // waves per SIMD the halo kernels are register-bounded for (4 would spill and exceed LDS anyway)
 #endif
@@ -845,8 +849,8 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     }
     const long tiles = (long)p->mtiles * p->ntiles * p->par;
     int sk = 1;
-    if (tiles < 256) {
-        sk = (int)((512 + tiles - 1) / tiles);
+    if (tiles < RNR_SPLITK_BELOW) {      // fewer workgroups than ~2-3 per CU: split K so the 256 CUs stay filled
+        sk = (int)((RNR_SPLITK_TARGET + tiles - 1) / tiles);
         // split granularity: K-chunks x taps for the gather kernel, K-chunks (all nine taps) for the halo kernel
         const int units = p->halo ? p->chunks_per_tap : p->kt_total / 4;
         const int max_sk = units > 0 ? units : 1;
