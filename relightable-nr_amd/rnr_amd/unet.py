@@ -84,7 +84,9 @@ class UNetPlan:
                 b[:c_out] = g(bias_key)
                 out.shift = b[None].repeat(self.N, 1).contiguous()
                 step['bias'] = b
-            self.ws_bytes = max(self.ws_bytes, self.L.rnr_conv_workspace_bytes(ctypes.byref(desc), self.N, s0.h, s0.w))
+            # split-K depends on the number of views actually passed at call time: size the scratch for every n <= N
+            for n_views in range(1, self.N + 1):
+                self.ws_bytes = max(self.ws_bytes, self.L.rnr_conv_workspace_bytes(ctypes.byref(desc), n_views, s0.h, s0.w))
             self.steps.append(step)
             return out
 

@@ -163,3 +163,19 @@ def test_unet_nf16_vs_oracle():
     ref = orc.unet_forward(sd, x)
     assert (y - ref).abs().max() < 5e-4, (y - ref).abs().max()
     assert orc.psnr(y, ref, peak=2.0) > 70
+
+
+def test_plan_built_for_many_views_runs_fewer():
+    """Split-K is chosen per call from the number of views passed; a plan sized for 4 views must also serve 1 or 3
+    (workspace sizing regression)."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import ops, testing
+    from rnr_amd.unet import UNetPlan
+    sd = testing.unet_state_dict(16, 8, 16, seed=7, use_gcn=False)
+    x = torch.randn(4, 16, 128, 128, generator=torch.Generator().manual_seed(3))
+    plan = UNetPlan(sd, 16, 8, 16, 5, (128, 128), 4, torch.device(DEV))
+    ref = orc.unet_forward(sd, x)
+    for n in (1, 3, 4):
+        raw = plan.forward(ops.nchw_to_nhwc(x[:n].to(DEV), plan.in_c_pad))
+        y = ops.nhwc_to_nchw(raw, 8, bias=plan.out_bias, apply_tanh=True).cpu()
+        assert (y - ref[:n]).abs().max() < 5e-4, n
