@@ -114,9 +114,12 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('RNR_BENCH_FORCE_DIST') == '1'     # the env switch exercises the RCCL path on 1 GPU
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)       # "nccl" is RCCL on ROCm
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)       # "nccl" is RCCL on ROCm
     from rnr_amd import scene
     from rnr_amd.pipeline import RNRPipeline
     sc = build_scene(args)
@@ -128,14 +131,14 @@ def main():
     ids = (np.arange(n_total) * 7) % 720
     allv = scene.spiral_views(args.img_size, ids)
     poses = {k: torch.from_numpy(v).to(dev) for k, v in allv.items()}
-    gathered = [torch.empty(world * V, 3, args.img_size, args.img_size, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty(world * V, 3, args.img_size, args.img_size, device=dev) for _ in range(2)] if use_dist else None
     pending = []
 
     def step(s):
         lo = (s * world + rank) * V
         sl = slice(lo, lo + V)
         img = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
-        if world > 1:
+        if use_dist:
             # frames over xGMI — the only exchange of the path.  Issued asynchronously (RCCL's own stream) so that the
             # gather of step s overlaps the rendering of step s+1; frame / gather buffers are double-buffered.
             pending.append(dist.all_gather_into_tensor(gathered[s & 1], img, async_op=True))
@@ -161,7 +164,7 @@ def main():
         _i[0] += 1
         return r
     pipe.unet.forward = timed_forward
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -169,12 +172,12 @@ def main():
         img = step(s)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pipe.unet.forward = orig_forward
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -205,13 +208,17 @@ def main():
         if world == 1 and V > 1:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
+            def one(s):
+                s %= n_total
+                return pipe.render(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1],
+                                   poses['R_inv'][s:s + 1])
             for s in range(3):
-                pipe.render(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1], poses['R_inv'][s:s + 1])
+                one(s)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n1 = 40
             for s in range(n1):
-                pipe.render(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1], poses['R_inv'][s:s + 1])
+                one(s)
             torch.cuda.synchronize()
             dt1 = (time.perf_counter() - t1) / n1
             res['single_view_mode'] = {'views_per_step': 1, 'ms_per_frame': dt1 * 1e3, 'frames_per_s': 1.0 / dt1}
@@ -224,9 +231,12 @@ def main():
                 res['parity'] = parity
         else:
             res['cpu_baseline'] = None
-        print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)     # RCCL's banner sits in C stdio's buffer when stdout is a pipe
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':
