@@ -68,6 +68,41 @@ int rnr_forward_texture_sampling(const float* faces, const float* textures, cons
                                  int batch_size, int num_faces, int image_size, int texture_size, float eps,
                                  void* stream);
 
+/*
+ * backward_pixel_map (rasterize_cuda.cpp:124-147 -> rasterize_cuda_kernel.cu:244-498, launch 693-732): gradient of
+ * the rgb / alpha maps with respect to the NDC x,y of the face vertices (the silhouette sweep of Kato et al.).
+ *   faces [B,nf,3,3]; face_index_map [B,is,is]; rgb_map / grad_rgb_map [B,is,is,3] (read when return_rgb);
+ *   alpha_map / grad_alpha_map [B,is,is] (read when return_alpha); grad_faces [B,nf,3,3] caller pre-fills 0
+ *   (rasterize.py:112): rows of front-facing faces are OVERWRITTEN, rows of back faces are left untouched.
+ * Maps are in the extension's native row order.  Each gradient entry is accumulated by one thread in the
+ * reference's order, so the result is bit-identical to the reference kernel run without FMA contraction.
+ * No-op when both flags are 0 (rasterize.py:203-204).
+ */
+int rnr_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
+                           const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
+                           float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
+                           int return_rgb, int return_alpha, void* stream);
+
+/*
+ * backward_textures (rasterize_cuda.cpp:149-165 -> rasterize_cuda_kernel.cu:500-535, launch 734-763):
+ *   grad_textures [B,nf,ts,ts,ts,3] += sampling_weight * grad_rgb at the 8 texels recorded by
+ *   rnr_forward_texture_sampling (caller pre-fills 0, rasterize.py:114).  Float atomics: summation order is
+ *   unspecified, as in the reference.
+ */
+int rnr_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+                          const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
+                          int batch_size, int num_faces, int image_size, int texture_size, void* stream);
+
+/*
+ * backward_depth_map (rasterize_cuda.cpp:167-189 -> rasterize_cuda_kernel.cu:537-592, launch 765-800): ADDS the
+ * gradient of the depth map to grad_faces [B,nf,3,3] (called after rnr_backward_pixel_map, rasterize.py:145-152).
+ *   depth_map [B,is,is]; face_inv_map [B,is,is,3,3] and weight_map [B,is,is,3] as written by
+ *   rnr_forward_face_index_map(return_depth = 1); grad_depth_map [B,is,is].  Float atomics (pre-reduced per wave).
+ */
+int rnr_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                           const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
+                           float* grad_faces, int batch_size, int num_faces, int image_size, void* stream);
+
 /* =====================================================================================================
  * 2. Fused hot path (one view batch = N camera poses of one mesh)
  * ===================================================================================================== */

@@ -71,3 +71,39 @@ def texture_sampling(faces, textures, fim, wm, dm, image_size, eps):
                                   _p(np.ascontiguousarray(dm, np.float32)), _p(rgb), _p(sim), _p(swm),
                                   B, nf, S, ts, ctypes.c_float(eps))
     return {'rgb_map': rgb, 'sampling_index_map': sim, 'sampling_weight_map': swm}
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dt)
+
+
+def backward_pixel_map(faces, fim, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, eps,
+                       return_rgb=True, return_alpha=True):
+    """-> grad_faces [B,nf,3,3] (zeros where the reference leaves the caller's zeros: back faces)."""
+    faces = _c(faces)
+    B, nf = faces.shape[:2]
+    gf = np.zeros((B, nf, 3, 3), np.float32)
+    args = [_c(rgb_map), _c(alpha_map), _c(grad_rgb_map), _c(grad_alpha_map)]
+    fim = _c(fim, np.int32)
+    lib().oracle_backward_pixel_map(_p(faces), _p(fim), _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(gf),
+                                    B, nf, int(image_size), ctypes.c_float(eps), int(return_rgb), int(return_alpha))
+    return gf
+
+
+def backward_textures(fim, sampling_weight_map, sampling_index_map, grad_rgb_map, num_faces, texture_size):
+    fim = _c(fim, np.int32)
+    B, S = fim.shape[:2]
+    ts = int(texture_size)
+    gt = np.zeros((B, num_faces, ts, ts, ts, 3), np.float32)
+    swm, sim, g = _c(sampling_weight_map), _c(sampling_index_map, np.int32), _c(grad_rgb_map)
+    lib().oracle_backward_textures(_p(fim), _p(swm), _p(sim), _p(g), _p(gt), B, int(num_faces), S, ts)
+    return gt
+
+
+def backward_depth_map(faces, depth_map, fim, face_inv_map, weight_map, grad_depth_map, image_size, grad_faces=None):
+    faces = _c(faces)
+    B, nf = faces.shape[:2]
+    gf = np.zeros((B, nf, 3, 3), np.float32) if grad_faces is None else _c(grad_faces).copy()
+    dm, fim, fivm, wm, gd = _c(depth_map), _c(fim, np.int32), _c(face_inv_map), _c(weight_map), _c(grad_depth_map)
+    lib().oracle_backward_depth_map(_p(faces), _p(dm), _p(fim), _p(fivm), _p(wm), _p(gd), _p(gf), B, nf, int(image_size))
+    return gf

@@ -167,3 +167,151 @@ void oracle_texture_sampling(const float* faces, const float* textures, const in
         for (int k = 0; k < 3; k++) rgb_map[3 * i + k] = acc[k];
     }
 }
+
+/* =====================================================================================================
+ * Backward passes (rasterize_cuda_kernel.cu:244-592).  Same arithmetic contract as above.
+ *   oracle_backward_pixel_map  <- cu:244-498   oracle_backward_textures <- cu:500-535
+ *   oracle_backward_depth_map  <- cu:537-592
+ * float -> int conversions follow the GPU rule the reference runs under (NaN -> 0, saturating), which
+ * x86's cvttss2si does not: gpu_int() makes it explicit.
+ * ===================================================================================================== */
+static inline int gpu_int(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483520.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int)x;
+}
+
+typedef struct {
+    const int32_t* fim; const float* rgb; const float* alpha; const float* g_rgb; const float* g_alpha;
+    int is, use_rgb, use_alpha; float eps;
+} sweep_ctx;
+
+/* d(loss)/d(pixel m) when pixel m would take the colour of reference pixel `ref` (cu:357-364, 454-461) */
+static float colour_delta(const sweep_ctx* c, long m, long ref) {
+    float d = 0.0f;
+    if (c->use_alpha) d += (c->alpha[m] - c->alpha[ref]) * c->g_alpha[m];
+    if (c->use_rgb)
+        for (int k = 0; k < 3; k++) d += (c->rgb[m * 3 + k] - c->rgb[ref * 3 + k]) * c->g_rgb[m * 3 + k];
+    return d;
+}
+
+/* One edge (a -> b, opposite vertex o) swept along one axis; q[.][0] is the sweep coordinate, q[.][1] the
+ * other one, all in pixel-index space.  ga / gb accumulate the gradient of vertex a / b's OTHER coordinate. */
+static void sweep_edge(const sweep_ctx* c, int fn, long base, int axis, const float q[3][2], float* ga, float* gb) {
+    const int is = c->is;
+    const float fis = (float)is;
+    const int dir = (axis == 0) ? (q[0][0] < q[1][0] ? -1 : 1) : (q[0][0] < q[1][0] ? 1 : -1);
+    const long step1 = axis == 0 ? is : 1, step0 = axis == 0 ? 1 : is;
+    const int from = gpu_int(fmaxf(ceilf(fminf(q[0][0], q[1][0])), 0.0f));
+    const int to = gpu_int(fminf(fmaxf(q[0][0], q[1][0]), fis - 1.0f));
+    for (int d0 = from; d0 <= to; d0++) {
+        const float x = (float)d0;
+        const float cross = (q[1][1] - q[0][1]) / (q[1][0] - q[0][0]) * (x - q[0][0]) + q[0][1];
+        const int in = gpu_int(dir > 0 ? floorf(cross) : ceilf(cross));
+        const int out = in + dir;
+        if (in < 0 || in >= is || out < 0 || out >= is) continue;
+        const long line = base + d0 * step0;
+        const long m_in = line + in * step1, m_out = line + out * step1;
+        for (int pass = 0; pass < 2; pass++) {
+            int lim;
+            if (pass == 0) {                                   /* outside run, needs the inner pixel to show fn */
+                if (c->fim[m_in] != fn) continue;
+                lim = dir > 0 ? is - 1 : 0;
+            } else {                                           /* inside run, up to the opposite edge */
+                float far_cross;
+                if ((x - q[0][0]) * (x - q[2][0]) < 0)
+                    far_cross = (q[2][1] - q[0][1]) / (q[2][0] - q[0][0]) * (x - q[0][0]) + q[0][1];
+                else
+                    far_cross = (q[1][1] - q[2][1]) / (q[1][0] - q[2][0]) * (x - q[2][0]) + q[2][1];
+                lim = gpu_int(dir > 0 ? ceilf(far_cross) : floorf(far_cross));
+            }
+            const int start = pass == 0 ? out : in;
+            int lo = start < lim ? start : lim, hi = start < lim ? lim : start;
+            if (lo < 0) lo = 0;
+            if (hi > is - 1) hi = is - 1;
+            for (int d1 = lo; d1 <= hi; d1++) {
+                const long m = line + d1 * step1;
+                if (pass == 1 && c->fim[m] != fn) continue;
+                const float dg = colour_delta(c, m, pass == 0 ? m_in : m_out);
+                if (dg <= 0) continue;
+                const float off = (float)d1 - cross;
+                if (q[1][0] != x) {
+                    float dist = (q[1][0] - q[0][0]) / (q[1][0] - x) * off * 2.0f / fis;
+                    dist = 0 < dist ? dist + c->eps : dist - c->eps;
+                    *ga -= dg / dist;
+                }
+                if (q[0][0] != x) {
+                    float dist = (q[1][0] - q[0][0]) / (x - q[0][0]) * off * 2.0f / fis;
+                    dist = 0 < dist ? dist + c->eps : dist - c->eps;
+                    *gb -= dg / dist;
+                }
+            }
+        }
+    }
+}
+
+void oracle_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
+                               const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
+                               float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
+                               int return_rgb, int return_alpha) {
+    if (!return_rgb && !return_alpha) return;
+    const sweep_ctx c = {face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, return_rgb,
+                         return_alpha, eps};
+    const long total = (long)batch_size * num_faces;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long i = 0; i < total; i++) {
+        const float* f = faces + i * 9;
+        if (is_backface(f)) continue;                     /* grad_faces row left as the caller filled it */
+        float g[9] = {0};
+        const long base = (i / num_faces) * (long)image_size * image_size;
+        for (int e = 0; e < 3; e++) {
+            const int a = e, b = (e + 1) % 3, o = (e + 2) % 3;
+            for (int axis = 0; axis < 2; axis++) {
+                float q[3][2];
+                const int v[3] = {a, b, o};
+                for (int n = 0; n < 3; n++)
+                    for (int d = 0; d < 2; d++) q[n][d] = ndc_to_pix(f[3 * v[n] + ((d + axis) & 1)], image_size);
+                sweep_edge(&c, (int)(i % num_faces), base, axis, q, &g[3 * a + (1 - axis)], &g[3 * b + (1 - axis)]);
+            }
+        }
+        for (int k = 0; k < 9; k++) grad_faces[i * 9 + k] = g[k];
+    }
+}
+
+/* serial (the reference's atomics have no defined order; tests compare with a tolerance) */
+void oracle_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+                              const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
+                              int batch_size, int num_faces, int image_size, int texture_size) {
+    const long pix = (long)image_size * image_size, cube = (long)texture_size * texture_size * texture_size * 3;
+    for (long i = 0; i < batch_size * pix; i++) {
+        const int fn = face_index_map[i];
+        if (fn < 0) continue;
+        float* gt = grad_textures + ((i / pix) * num_faces + fn) * cube;
+        for (int s = 0; s < 8; s++)
+            for (int k = 0; k < 3; k++)
+                gt[(long)sampling_index_map[i * 8 + s] * 3 + k] += sampling_weight_map[i * 8 + s] * grad_rgb_map[i * 3 + k];
+    }
+}
+
+void oracle_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                               const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
+                               float* grad_faces, int batch_size, int num_faces, int image_size) {
+    const long pix = (long)image_size * image_size;
+    for (long i = 0; i < batch_size * pix; i++) {
+        const int fn = face_index_map[i];
+        if (fn < 0) continue;
+        const long fi = (i / pix) * num_faces + fn;
+        const float* f = faces + fi * 9;
+        const float* inv = face_inv_map + i * 9;
+        const float* w = weight_map + i * 3;
+        const float d2 = depth_map[i] * depth_map[i], gd = grad_depth_map[i];
+        float* g = grad_faces + fi * 9;
+        for (int k = 0; k < 3; k++) g[3 * k + 2] += gd * w[k] * d2 / (f[3 * k + 2] * f[3 * k + 2]);
+        float t[2] = {0.0f, 0.0f};
+        for (int k = 0; k < 2; k++)
+            for (int l = 0; l < 3; l++) t[k] += -inv[3 * l + k] / f[3 * l + 2];
+        for (int k = 0; k < 3; k++)
+            for (int l = 0; l < 2; l++) g[3 * k + l] += -gd * t[l] * w[k] * d2 * (float)image_size / 2.0f;
+    }
+}

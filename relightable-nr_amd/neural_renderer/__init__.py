@@ -3,8 +3,9 @@
 (`nr.load_obj`, `nr.Renderer`, `nr.projection`, `nr.lighting`, `nr.vertices_to_faces`,
 `nr.vertex_attrs_to_faces`, `nr.rasterize_rgbad`, `nr.Rasterize`, ...), backed by librnr_hip.so.
 
-Out of scope: look / look_at / perspective camera modes, Mesh helper, save_obj, texture loading,
-and the backward kernels; those names raise NotImplementedError instead of silently misbehaving.
+The rasterizer is differentiable (RasterizeFunction: HIP backward kernels for the rgb/alpha/depth maps and textures).
+Out of scope (SURVEY.md §2.1): look / look_at / perspective camera modes, Mesh helper, save_obj, texture loading;
+those names raise NotImplementedError instead of silently misbehaving.
 """
 from .lighting import lighting
 from .load_obj import load_obj

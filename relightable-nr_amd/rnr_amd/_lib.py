@@ -51,6 +51,9 @@ SIGNATURES = {
     'rnr_forward_face_index_map': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int,
                                                             c_int, c_void_p, c_void_p]),
     'rnr_forward_texture_sampling': (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    'rnr_backward_pixel_map': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    'rnr_backward_textures': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
+    'rnr_backward_depth_map': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     'rnr_project_vertices': (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_void_p]),
     'rnr_gbuffer_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'rnr_rasterize_gbuffer': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_float, P(RnrGbuffer),

@@ -68,6 +68,52 @@ def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_
     return [rgb_map, sampling_index_map, sampling_weight_map]
 
 
+def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, image_size,
+                       eps, return_rgb, return_alpha):
+    """rasterize_cuda.cpp:124-147.  grad_faces [B,nf,3,3] (pre-filled 0) is written in place and returned; the maps a
+    flag switches off are placeholders and are not read (rasterize.py:118-131)."""
+    L = _lib.load()
+    _chk(faces, 'faces'); _chk(face_index_map, 'face_index_map', torch.int32); _chk(grad_faces, 'grad_faces')
+    if return_rgb:
+        _chk(rgb_map, 'rgb_map'); _chk(grad_rgb_map, 'grad_rgb_map')
+    if return_alpha:
+        _chk(alpha_map, 'alpha_map'); _chk(grad_alpha_map, 'grad_alpha_map')
+    B, nf = faces.shape[0], faces.shape[1]
+    check(L.rnr_backward_pixel_map(_ptr(faces), _ptr(face_index_map), _ptr(rgb_map if return_rgb else None),
+                                   _ptr(alpha_map if return_alpha else None),
+                                   _ptr(grad_rgb_map if return_rgb else None),
+                                   _ptr(grad_alpha_map if return_alpha else None), _ptr(grad_faces), B, nf,
+                                   int(image_size), float(eps), int(return_rgb), int(return_alpha), _stream()))
+    return grad_faces
+
+
+def backward_textures(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, num_faces):
+    """rasterize_cuda.cpp:149-165.  grad_textures [B,nf,ts,ts,ts,3] (pre-filled 0) accumulated in place."""
+    L = _lib.load()
+    _chk(face_index_map, 'face_index_map', torch.int32); _chk(sampling_weight_map, 'sampling_weight_map')
+    _chk(sampling_index_map, 'sampling_index_map', torch.int32); _chk(grad_rgb_map, 'grad_rgb_map')
+    _chk(grad_textures, 'grad_textures')
+    B, S = face_index_map.shape[0], face_index_map.shape[1]
+    check(L.rnr_backward_textures(_ptr(face_index_map), _ptr(sampling_weight_map), _ptr(sampling_index_map),
+                                  _ptr(grad_rgb_map), _ptr(grad_textures), B, int(num_faces), S,
+                                  int(grad_textures.shape[2]), _stream()))
+    return grad_textures
+
+
+def backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
+                       image_size):
+    """rasterize_cuda.cpp:167-189.  Adds the depth-map gradient to grad_faces in place."""
+    L = _lib.load()
+    _chk(faces, 'faces'); _chk(depth_map, 'depth_map'); _chk(face_index_map, 'face_index_map', torch.int32)
+    _chk(face_inv_map, 'face_inv_map'); _chk(weight_map, 'weight_map'); _chk(grad_depth_map, 'grad_depth_map')
+    _chk(grad_faces, 'grad_faces')
+    B, nf = faces.shape[0], faces.shape[1]
+    check(L.rnr_backward_depth_map(_ptr(faces), _ptr(depth_map), _ptr(face_index_map), _ptr(face_inv_map),
+                                   _ptr(weight_map), _ptr(grad_depth_map), _ptr(grad_faces), B, nf, int(image_size),
+                                   _stream()))
+    return grad_faces
+
+
 # ---------------------------------------------------------------------------------------------------
 # fused path
 # ---------------------------------------------------------------------------------------------------

@@ -3,8 +3,8 @@
 The reference rasterizer has no CPU path (neural_renderer/rasterize.py:17-19) and its extension needs
 CUDA headers / nvcc that this image lacks, so a reference build (`oracle/_ref`) is not possible.
 To still pin the oracle to the reference's own arithmetic, this harness copies
-lines 23-242 of /root/reference/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu
-(the three forward __global__ templates) into a TEMP directory, prepends a thread-index shim
+lines 23-592 of /root/reference/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu
+(the three forward and three backward __global__ templates) into a TEMP directory, prepends a thread-index shim
 (blockIdx/blockDim/threadIdx as thread-locals, CUDA's fmin/fmax-semantics min/max overloads), and
 drives the kernels with a serial loop over thread ids.  Nothing of the reference is written into
 the repository: only the produced (input, output) vectors are committed by make_golden.py.
@@ -17,7 +17,7 @@ import tempfile
 import numpy as np
 
 REF_CU = '/root/reference/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu'
-FIRST, LAST = 23, 242
+FIRST, LAST = 23, 592
 
 _SHIM_HEAD = r'''
 #include <cstdint>
@@ -35,6 +35,10 @@ static inline float  max(float a, float b)  { return fmaxf(a, b); }
 static inline double min(double a, double b) { return fmin(a, b); }
 static inline double min(float a, double b) { return fmin((double)a, b); }
 static inline float  min(float a, float b)  { return fminf(a, b); }
+static inline int    max(int a, int b) { return a > b ? a : b; }
+static inline int    min(int a, int b) { return a < b ? a : b; }
+/* the driver below is serial, so a plain add has atomicAdd's semantics */
+template <typename T> static inline void atomicAdd(T* p, T v) { *p += v; }
 namespace {
 '''
 
@@ -66,6 +70,36 @@ void ref_texture_sampling(const float* faces, const float* textures, const int32
         forward_texture_sampling_cuda_kernel<float>(faces, textures, face_index_map, weight_map, depth_map,
             rgb_map, sampling_index_map, sampling_weight_map, (size_t)batch_size, num_faces, image_size,
             texture_size, eps);
+    }
+}
+void ref_backward_pixel_map(const float* faces, int32_t* face_index_map, float* rgb_map, float* alpha_map,
+                            float* grad_rgb_map, float* grad_alpha_map, float* grad_faces, int batch_size,
+                            int num_faces, int image_size, float eps, int return_rgb, int return_alpha) {
+    blockDim.x = 1; threadIdx.x = 0;
+    for (long i = 0; i < (long)batch_size * num_faces; i++) {
+        blockIdx.x = (unsigned)i;
+        backward_pixel_map_cuda_kernel<float>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,
+            grad_faces, (size_t)batch_size, (size_t)num_faces, image_size, eps, return_rgb, return_alpha);
+    }
+}
+void ref_backward_textures(const int32_t* face_index_map, float* sampling_weight_map, int32_t* sampling_index_map,
+                           float* grad_rgb_map, float* grad_textures, int batch_size, int num_faces, int image_size,
+                           int texture_size) {
+    blockDim.x = 1; threadIdx.x = 0;
+    for (long i = 0; i < (long)batch_size * image_size * image_size; i++) {
+        blockIdx.x = (unsigned)i;
+        backward_textures_cuda_kernel<float>(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map,
+            grad_textures, (size_t)batch_size, (size_t)num_faces, image_size, (size_t)texture_size);
+    }
+}
+void ref_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                            const float* face_inv_map, const float* weight_map, float* grad_depth_map,
+                            float* grad_faces, int batch_size, int num_faces, int image_size) {
+    blockDim.x = 1; threadIdx.x = 0;
+    for (long i = 0; i < (long)batch_size * image_size * image_size; i++) {
+        blockIdx.x = (unsigned)i;
+        backward_depth_map_cuda_kernel<float>(faces, depth_map, face_index_map, face_inv_map, weight_map,
+            grad_depth_map, grad_faces, (size_t)batch_size, (size_t)num_faces, image_size);
     }
 }
 }
@@ -128,6 +162,44 @@ def texture_sampling(faces, textures, fim, wm, dm, image_size, eps):
                              _p(np.ascontiguousarray(dm)), _p(rgb), _p(sim), _p(swm), B, nf, S, ts,
                              ctypes.c_float(eps))
     return {'rgb_map': rgb, 'sampling_index_map': sim, 'sampling_weight_map': swm}
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dt)
+
+
+def backward_pixel_map(faces, fim, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, eps,
+                       return_rgb=1, return_alpha=1):
+    lib = build()
+    faces = _c(faces)
+    B, nf = faces.shape[:2]
+    gf = np.zeros((B, nf, 3, 3), np.float32)
+    a = [_c(fim, np.int32), _c(rgb_map), _c(alpha_map), _c(grad_rgb_map), _c(grad_alpha_map)]
+    lib.ref_backward_pixel_map(_p(faces), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(gf), B, nf,
+                               int(image_size), ctypes.c_float(eps), int(return_rgb), int(return_alpha))
+    return gf
+
+
+def backward_textures(fim, swm, sim, grad_rgb_map, num_faces, texture_size):
+    lib = build()
+    fim = _c(fim, np.int32)
+    B, S = fim.shape[:2]
+    ts = int(texture_size)
+    gt = np.zeros((B, num_faces, ts, ts, ts, 3), np.float32)
+    a = [_c(swm), _c(sim, np.int32), _c(grad_rgb_map)]
+    lib.ref_backward_textures(_p(fim), _p(a[0]), _p(a[1]), _p(a[2]), _p(gt), B, int(num_faces), S, ts)
+    return gt
+
+
+def backward_depth_map(faces, depth_map, fim, face_inv_map, weight_map, grad_depth_map, image_size):
+    lib = build()
+    faces = _c(faces)
+    B, nf = faces.shape[:2]
+    gf = np.zeros((B, nf, 3, 3), np.float32)
+    a = [_c(depth_map), _c(fim, np.int32), _c(face_inv_map), _c(weight_map), _c(grad_depth_map)]
+    lib.ref_backward_depth_map(_p(faces), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(gf), B, nf,
+                               int(image_size))
+    return gf
 
 
 if __name__ == '__main__':

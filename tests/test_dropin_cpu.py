@@ -52,8 +52,12 @@ def test_neural_renderer_api_names():
         assert hasattr(ext, name)
     with pytest.raises(NotImplementedError):
         nr.look_at(None, None)
-    with pytest.raises(NotImplementedError):
-        ext.backward_textures()
+    with pytest.raises(RuntimeError):          # real HIP kernels now: CPU tensors are rejected like CHECK_INPUT does
+        ext.backward_textures(torch.zeros(1, 4, 4, dtype=torch.int32), torch.zeros(1, 4, 4, 8),
+                              torch.zeros(1, 4, 4, 8, dtype=torch.int32), torch.zeros(1, 4, 4, 3),
+                              torch.zeros(1, 2, 2, 2, 2, 3), 2)
+    assert issubclass(nr.rasterize.RasterizeFunction, torch.autograd.Function) if hasattr(nr.rasterize, 'RasterizeFunction') \
+        else True
 
 
 def test_load_obj_matches_reference_parser(golden, tmp_path):

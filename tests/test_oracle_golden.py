@@ -44,6 +44,26 @@ def test_raster_texture_sampling_bit_exact(golden):
     assert np.array_equal(bits(r['sampling_weight_map']), bits(g['sampling_weight_map']))
 
 
+@pytest.mark.parametrize('name', ['raster_bwd_soup48', 'raster_bwd_soup64_ts2'])
+def test_raster_backward_c_bit_exact(golden, name):
+    """Backward kernels (rasterize_cuda_kernel.cu:244-592): the C restatement reproduces the reference kernels' serial
+    run bit for bit (pixel map: fixed accumulation order; textures / depth: the serial order of the golden run)."""
+    from oracle import raster as oras
+    g = golden(name)
+    S, eps, nf = int(g['image_size']), float(g['eps']), g['faces'].shape[1]
+    for tag, rr, ra in [('both', 1, 1), ('alpha', 0, 1), ('rgb', 1, 0)]:
+        o = oras.backward_pixel_map(g['faces'], g['face_index_map'], g['rgb_map'], g['alpha_map'], g['grad_rgb_map'],
+                                    g['grad_alpha_map'], S, eps, rr, ra)
+        assert np.array_equal(o.view(np.uint32), g['grad_faces_pixel_' + tag].view(np.uint32)), tag
+    o = oras.backward_textures(g['face_index_map'], g['sampling_weight_map'], g['sampling_index_map'], g['grad_rgb_map'],
+                               nf, int(g['texture_size']))
+    assert np.array_equal(o, g['grad_textures'])
+    o = oras.backward_depth_map(g['faces'], g['depth_map'], g['face_index_map'], g['face_inv_map'], g['weight_map'],
+                                g['grad_depth_map'], S)
+    assert np.array_equal(o, g['grad_faces_depth'])
+    assert np.abs(g['grad_faces_pixel_both']).max() > 1 and np.abs(g['grad_faces_depth']).max() > 1      # not vacuous
+
+
 def test_projection(golden):
     g = golden('projection')
     a = orc.projection(T(g['vertices']), T(g['K']), T(g['R']), T(g['t']), torch.zeros(1, 5), int(g['orig_size']))
