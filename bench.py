@@ -205,6 +205,30 @@ def main():
                          'traffic_source': traffic_src,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms},
         }
+        # per-stage HIP events (5 extra steps outside the timed region): the non-conv stages against the HBM roofline
+        P_px = args.img_size * args.img_size
+        m = sc['mesh']
+        T_tex = sum(int(t.shape[-3]) * int(t.shape[-2]) for t in sc['textures'])
+        mesh_b = 12 * len(m['v']) + 8 * len(m['vt']) + 12 * len(m['vn']) + 36 * len(m['f_v_idx'])
+        alg = {       # algorithmic bytes per VIEW: compulsory reads + writes of each fused stage
+            'raster': mesh_b + 28 * P_px,                                           # idx 4 + alpha 4 + uv 8 + normal 12
+            'shade_inputs': 28 * P_px + 4 * args.tex_ch * T_tex + 4 * sc['c_in'] * P_px,
+            'ray_render': 4 * 3 * sc['n_rays'] * P_px + 4 * (3 * sc['n_rays'] + 6) * P_px + 4 * P_px + 12 * P_px,
+        }
+        acc = {}
+        n_prof = 5
+        for s in range(n_prof):
+            evs = []
+            lo = (s % (args.steps + args.warmup)) * world * V
+            sl = slice(lo, lo + V)
+            pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl], stage_events=evs)
+            torch.cuda.synchronize()
+            for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1) / n_prof
+        res['stages'] = {k: {'ms_per_step': acc[k],
+                             **({'alg_bytes_per_step': alg[k] * V, 'GB/s': alg[k] * V / (acc[k] * 1e-3) / 1e9,
+                                 'frac_of_hbm_peak': alg[k] * V / (acc[k] * 1e-3) / 1e9 / PEAK_HBM_GBS} if k in alg else {})}
+                         for k in acc}
         if world == 1 and V > 1:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)

@@ -75,9 +75,18 @@ class RNRPipeline:
         lp = torch.as_tensor(lp, dtype=torch.float32)
         self.lp = lp.reshape(lp.shape[-3], lp.shape[-2], 3).contiguous().to(self.dev)
 
-    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False, lighting_idx=0):
+    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False, lighting_idx=0, stage_events=None):
         """proj/proj_inv/R_inv [N,3,3], pose [N,4,4] device float32 -> image [N,3,S,S].  The result is a view into one of
-        two internal buffers used alternately: it stays valid until the call after next."""
+        two internal buffers used alternately: it stays valid until the call after next.
+        stage_events: optional list; (name, torch.cuda.Event) pairs are appended at the stage boundaries
+        (measurement only — bench.py's per-stage HBM figures)."""
+
+        def mark(name):
+            if stage_events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                stage_events.append((name, e))
+        mark('start')
         N = proj.shape[0]
         if N > self.max_views:
             raise RuntimeError('pipeline built for max_views=%d, got %d poses' % (self.max_views, N))
@@ -88,14 +97,18 @@ class RNRPipeline:
         gb = {m: self._gb[m][:N] for m in self._gb_maps}
         ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
                               workspace=self._ws)
+        mark('raster')
         self.mesh._tangents = None          # per-face tangents recomputed per call, as get_TBN_map does (render.py:135-150)
         lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
         sh = ops.shade_inputs(gb, self.mesh, proj_inv.contiguous(), R_inv.contiguous(), self.textures,
                               self.pivots_spec, self.pivots_diff, self.sh_start_ch, c_pad=self.unet.in_c_pad,
                               net_in=self._net_in[:N])
+        mark('shade_inputs')
         raw = self.unet.forward(sh['net_in'], N)
+        mark('unet')
         img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff,
                              albedo_diff_ch=0, albedo_spec_ch=3, image=self._images[self._flip][:N])
+        mark('ray_render')
         self._flip ^= 1
         if keep_intermediates:
             self.last = {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}
