@@ -182,7 +182,8 @@ conv_mfma_kernel(const ConvParams P) {
             }
             areg[p] = v;
         }
-        const size_t krow0 = ((size_t)(par * TAPS + tp) * P.chunks_per_tap + ch) * BK;
+        // packed weights are plane images per chunk, [4 g][wstride][4 e] (see conv_halo_kernel / pack_weight_kernel)
+        const float* wchunk = P.weight + ((size_t)(par * TAPS + tp) * P.chunks_per_tap + ch) * (16 * (size_t)P.wstride);
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
             const int idx = tid + CTHREADS * b;
@@ -190,7 +191,10 @@ conv_mfma_kernel(const ConvParams P) {
             if (idx < BQ) {
                 const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
                 const int col = n0 + 4 * c4;
-                if (col < P.c_out_pad) w = *reinterpret_cast<const float4*>(P.weight + (krow0 + kr) * P.wstride + col);
+                if (col < P.c_out_pad) {
+                    const float* wp = wchunk + ((size_t)(2 * (kr & 1) + (kr >> 3)) * P.wstride + col) * 4 + ((kr >> 1) & 3);
+                    w = make_float4(wp[0], wp[4], wp[8], wp[12]);
+                }
             }
             breg[b] = w;
         }
@@ -371,24 +375,27 @@ conv_halo_kernel(const ConvParams P) {
     constexpr int HWD = KIND == 1 ? 2 * TW + 2 : TW + 2;   // halo width  34 / 66
     constexpr int HHT = KIND == 1 ? 2 * TH + 2 : TH + 2;   // halo height
     constexpr int HP = HWD * HHT;
-    constexpr int LDA = HP;                                // 340, 204, 660: 4*LDA % 32 == 16 -> <= 2-way ds_write conflicts
-    constexpr int ASLOTS = HP * 4;                         // float4 slots of one halo chunk
+    constexpr int ASLOTS = HP * 4;                         // float4 slots of one halo chunk (pixel x channel quad)
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
     constexpr int APS = (APT + TAPS - 1) / TAPS;           // halo float4 fetched per pipeline step
     // The 4x4-s2 halo (660 px) double-buffered would leave room for one workgroup per CU only (MFMA pipe 53 % busy,
     // profiles/r01_pmc_per_kernel_v4): keep ONE LDS copy, carry the next chunk's halo in registers across the 16 taps
     // and swap it in between chunks (one extra barrier per chunk) -> two workgroups per CU.
     constexpr int ABUFS = KIND == 1 ? 1 : 2;
-    constexpr int LDB = BN;                                // unpadded: the weight tile is DMA'd (global_load_lds) linearly
-    constexpr int BQ = BK * BN / 4;
-    constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
-    static_assert(BQ % 64 == 0, "whole waves per DMA pass");
-    static_assert(LDA % 8 == 4, "LDA chosen for <= 2-way ds_write bank conflicts");
+    // LDS image of one 16-channel chunk, for the halo (X = HP pixels) and for the weight tile (X = BN columns):
+    //   [4 planes g][X][4 floats e],  channel k of the chunk -> g = 2*(k&1) + (k>>3), e = (k>>1)&3.
+    // An MFMA lane (x, h) needs channels k = 2s+h, s = 0..7, of ONE pixel / column: that is planes 2h and 2h+1 at
+    // lane-consecutive float4s -> two conflict-free ds_read_b128 per operand row per tap, every address an immediate
+    // offset from one per-lane base (the old [k][X] image took 16 ds_read_b32 and a VALU add per pair).
+    constexpr int ACH = 16 * HP, BCH = 16 * BN;            // floats per chunk image
+    constexpr int NPB = 4 * ((BN + 63) / 64);              // DMA pieces (<= 64 columns of one plane) per weight tile
+    constexpr int BPT = (NPB + 3) / 4;                     // pieces per wave
     static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+    static_assert(BK == 16, "plane mapping assumes 16-channel chunks");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [ABUFS][BK*LDA]
-    float* Bs = smem + ABUFS * BK * LDA;    // [2][BK*LDB]
+    float* As = smem;                       // [ABUFS][ACH]
+    float* Bs = smem + ABUFS * ACH;         // [2][BCH]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -408,27 +415,31 @@ conv_halo_kernel(const ConvParams P) {
     const int trem = mt_ - n * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 
-    // halo slots of this thread: fixed source pixels for the whole K loop
+    // halo slots of this thread: fixed source pixels for the whole K loop.  Slots past the halo repeat an earlier slot
+    // (same value to the same LDS address), the zero border of the transposed conv is a 0/1 factor: no branches.
     const int q = tid & 3;
-    int spix[APT], sdst[APT];
+    unsigned spix[APT];      // pixel index inside the view
+    int sdst[APT];           // float index of the (x, z) pair inside a chunk image; the (y, w) pair is 2 planes on
+    float smask[KIND == 2 ? APT : 1];
 #pragma unroll
     for (int j = 0; j < APT; j++) {
-        const int s = tid + CTHREADS * j;
+        int s = tid + CTHREADS * j;
+        if (s >= ASLOTS) s -= ASLOTS;
         const int hp = s >> 2;
-        spix[j] = -1;           // -1: slot beyond the halo;  -2: zero border (KIND 2)
-        sdst[j] = 0;
-        if (s < ASLOTS) {
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            int iy, ix, col = hx;
-            if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
-            else if (KIND == 1) {
-                iy = reflect1(2 * y0 - 1 + hy, P.H); ix = reflect1(2 * x0 - 1 + hx, P.W);
-                col = (hx & 1) * (HWD / 2) + (hx >> 1);                 // de-interleave even | odd columns
-            } else { iy = y0 - 1 + hy; ix = x0 - 1 + hx; }
-            sdst[j] = (4 * q) * LDA + hy * HWD + col;
-            if (KIND == 2 && (iy < 0 || iy >= P.H || ix < 0 || ix >= P.W)) spix[j] = -2;
-            else spix[j] = (n * P.H + iy) * P.W + ix;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        int iy, ix, col = hx;
+        if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
+        else if (KIND == 1) {
+            iy = reflect1(2 * y0 - 1 + hy, P.H); ix = reflect1(2 * x0 - 1 + hx, P.W);
+            col = (hx & 1) * (HWD / 2) + (hx >> 1);                 // de-interleave even | odd columns
+        } else {
+            iy = y0 - 1 + hy; ix = x0 - 1 + hx;
+            const bool inside = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            smask[j] = inside ? 1.f : 0.f;                          // exactly 0 outside, not act(shift)
+            iy = min(max(iy, 0), P.H - 1); ix = min(max(ix, 0), P.W - 1);
         }
+        sdst[j] = ((q >> 1) * HP + hy * HWD + col) * 4 + 2 * (q & 1);
+        spix[j] = (unsigned)(iy * P.W + ix);
     }
 
     const int nchunks = P.chunks_per_tap;
@@ -436,55 +447,62 @@ conv_halo_kernel(const ConvParams P) {
     const int c_begin = split * per_split;
     const int c_end = min(nchunks, c_begin + per_split);
 
-    struct ChunkSrc { const float* data; int C, cc, act; float4 sc, sh; };
+    // view base + channel offset are wave-uniform (SGPR pair); the per-lane part is a 32-bit element offset
+    // (make_plan keeps H*W*C below 2^30), so a halo fetch is one global_load_dwordx4 v, voff, s[base] and one VALU mad.
+    struct ChunkSrc { const float* base; unsigned C; int act; float4 sc, sh; };
     auto chunk_src = [&](int c) {
         ChunkSrc cs;
         const int s = c < P.chunks0 ? 0 : 1;
-        cs.cc = (c - (s ? P.chunks0 : 0)) * BK + 4 * q;
-        cs.C = P.src_c[s];
-        cs.data = P.src_data[s];
+        const int cc = (c - (s ? P.chunks0 : 0)) * BK;
+        cs.C = (unsigned)P.src_c[s];
+        cs.base = P.src_data[s] + (size_t)n * P.H * P.W * cs.C + cc;
         cs.act = P.src_act[s];
         cs.sc = make_float4(1.f, 1.f, 1.f, 1.f);
         cs.sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.src_scale[s]) cs.sc = *reinterpret_cast<const float4*>(P.src_scale[s] + (size_t)n * cs.C + cs.cc);
-        if (P.src_shift[s]) cs.sh = *reinterpret_cast<const float4*>(P.src_shift[s] + (size_t)n * cs.C + cs.cc);
+        if (P.src_scale[s]) cs.sc = *reinterpret_cast<const float4*>(P.src_scale[s] + (size_t)n * cs.C + cc + 4 * q);
+        if (P.src_shift[s]) cs.sh = *reinterpret_cast<const float4*>(P.src_shift[s] + (size_t)n * cs.C + cc + 4 * q);
         return cs;
     };
     auto load_a = [&](const ChunkSrc& cs, int j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (spix[j] >= 0) v = *reinterpret_cast<const float4*>(cs.data + (size_t)spix[j] * cs.C + cs.cc);
-        return v;
+        const unsigned voff = spix[j] * cs.C + 4u * (unsigned)q;
+        return *reinterpret_cast<const float4*>(cs.base + voff);
     };
     auto store_a = [&](const ChunkSrc& cs, float4 v, int j, int buf) {
-        if (spix[j] != -1) {
-            float* a = As + buf * (BK * LDA) + sdst[j];
-            if (KIND == 2 && spix[j] == -2) {       // zero border of the transposed conv: exactly 0, not act(shift)
-                a[0 * LDA] = 0.f; a[1 * LDA] = 0.f; a[2 * LDA] = 0.f; a[3 * LDA] = 0.f;
-            } else {
-                a[0 * LDA] = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
-                a[1 * LDA] = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
-                a[2 * LDA] = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
-                a[3 * LDA] = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
-            }
-        }
+        float x = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
+        float y = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
+        float z = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
+        float w = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
+        if (KIND == 2) { x *= smask[j]; y *= smask[j]; z *= smask[j]; w *= smask[j]; }
+        float* a = As + buf * ACH + sdst[j];
+        *reinterpret_cast<float2*>(a) = make_float2(x, z);                  // channels 4q, 4q+2   (h = 0 planes)
+        *reinterpret_cast<float2*>(a + 2 * HP * 4) = make_float2(y, w);     // channels 4q+1, 4q+3 (h = 1 planes)
     };
-    // Weight tile of one (chunk, tap): BK rows x BN floats, contiguous per row in the packed layout (row stride
-    // P.wstride >= ntiles*BN, so no column masking).  It goes global -> LDS by DMA (global_load_lds_dwordx4: no VGPRs,
-    // no ds_write; LDS image = wave-uniform base + lane*16 B, i.e. exactly the linear [BK][BN] tile).  The barrier
-    // that ends the step drains it (hipcc emits vmcnt(0) before s_barrier while an LDS-DMA is in flight).
+    // Weight tile of one (chunk, tap): the packed layout (pack_weight_kernel) already is the plane image, per chunk
+    // [4][wstride][4] floats, so a tile is 4 runs of BN float4 starting at column n0.  It goes global -> LDS by DMA
+    // (global_load_lds_dwordx4: no VGPRs, no ds_write; LDS image = wave-uniform base + lane*16 B) in pieces of <= 64
+    // columns.  The barrier that ends the step drains it (hipcc emits vmcnt(0) before s_barrier while an LDS-DMA is
+    // in flight).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int RUNS = (BN + 63) / 64;
+    unsigned bvoff[BPT];     // per-lane float offset of this wave's piece b inside a (chunk, tap) weight block
+    int blds[BPT];           // wave-uniform float offset of the piece inside a weight tile image
+    bool blive[BPT];         // lane takes part (pieces of 64 columns: all lanes; the 16-column tail: 16 lanes)
+#pragma unroll
+    for (int b = 0; b < BPT; b++) {
+        const int pc = wave_u + 4 * b;                      // piece = (plane, 64-column run), wave-uniform
+        const int g = pc / RUNS, run = pc - g * RUNS;
+        bvoff[b] = ((unsigned)g * (unsigned)P.wstride + (unsigned)(n0 + 64 * run + lane)) * 4u;
+        blds[b] = (g * BN + 64 * run) * 4;
+        blive[b] = pc < NPB && (BN % 64 == 0 || lane < BN - 64 * run);
+    }
     auto dma_b = [&](int c, int t, int buf) {
-        const size_t krow0 = ((size_t)(par * TAPS + t) * nchunks + c) * BK;
+        const float* wt = P.weight + ((size_t)(par * TAPS + t) * nchunks + c) * (16 * (size_t)P.wstride);
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
-            const int idx0 = wave_u * 64 + CTHREADS * b;           // first slot of this wave in pass b (wave-uniform)
-            if (idx0 < BQ) {
-                const int idx = idx0 + lane;
-                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
-                const float* g = P.weight + (krow0 + kr) * P.wstride + n0 + 4 * c4;
-                float* l = Bs + buf * (BK * LDB) + idx0 * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+            if ((NPB % 4 == 0 && BN % 64 == 0) || blive[b]) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + bvoff[b]),
+                                                 (__attribute__((address_space(3))) void*)(Bs + buf * BCH + blds[b]),
+                                                 16, 0, 0);
             }
         }
     };
@@ -500,6 +518,14 @@ conv_halo_kernel(const ConvParams P) {
     floatx4 acc16[R16 ? 2 * WM : 1];
 #pragma unroll
     for (int i = 0; i < (R16 ? 2 * WM : 1); i++) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS bases (floats): plane pair of this lane's k parity, its pixel / column, the wave's rows
+    const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const float* a_lane = As + ((2 * h) * HP + wrow + l31) * 4;
+    const float* b_lane = Bs + ((2 * h) * BN + wn0 + l31) * 4;
+    const int g16 = (kq & 1) * 2 + (kq >> 1);
+    const float* a16_lane = As + (g16 * HP + wrow + l15) * 4;
+    const float* b16_lane = Bs + (g16 * BN + wn0 + WN * 32 + l15) * 4;
 
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
@@ -517,7 +543,7 @@ conv_halo_kernel(const ConvParams P) {
 #pragma unroll
         for (int t = 0; t < TAPS; t++, step++) {
             const bool more = next_chunk || t < TAPS - 1;
-#ifndef RNR_ABLATE_NOLOAD
+#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_B)
             if (more) {
                 if (t < TAPS - 1) dma_b(c, t + 1, (step + 1) & 1); else dma_b(c + 1, 0, (step + 1) & 1);
             }
@@ -527,55 +553,49 @@ conv_halo_kernel(const ConvParams P) {
             for (int u = 0; u < APS; u++) {
                 const int j = t * APS + u;
                 av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef RNR_ABLATE_NOLOAD
+#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
                 if (next_chunk && j < APT) {
                     av[u] = load_a(csn, j);
                     if (ABUFS == 1) av_all[j] = av[u];
                 }
 #endif
             }
-            // LDS element of output row (wave_m*WM + i), lane x for this tap
+            // halo pixel of output row (wave_m*WM + i), lane x for this tap: compile-time part here, the parity shift
+            // of the transposed conv and the wave's row block are in a_lane
             int aoff;
-            if (KIND == 0) aoff = (wave_m * WM + t / 3) * HWD + (t % 3);
-            else if (KIND == 1) aoff = (2 * wave_m * WM + (t >> 2)) * HWD + ((t & 3) & 1) * (HWD / 2) + ((t & 3) >> 1);
-            else {
-                const int ty = t >> 1, tx = t & 1;
-                const int oy = py == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
-                const int ox = px == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
-                aoff = (wave_m * WM + oy) * HWD + ox;
+            if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
+            else if (KIND == 1) aoff = (t >> 2) * HWD + ((t & 3) & 1) * (HWD / 2) + ((t & 3) >> 1);
+            else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
+            constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;      // halo pixels between consecutive output rows
+            const float* a_s = a_lane + abuf * ACH + aoff * 4;
+            const float* b_s = b_lane + (step & 1) * BCH;
+#pragma unroll
+            for (int sg = 0; sg < 2; sg++) {
+                floatx4 a4[WM], b4[WN];
+#pragma unroll
+                for (int i = 0; i < WM; i++) a4[i] = *reinterpret_cast<const floatx4*>(a_s + (sg * HP + i * ROWSTEP) * 4);
+#pragma unroll
+                for (int j = 0; j < WN; j++) b4[j] = *reinterpret_cast<const floatx4*>(b_s + (sg * BN + 32 * j) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int i = 0; i < WM; i++)
+#pragma unroll
+                        for (int j = 0; j < WN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], b4[j][e], acc[i][j], 0, 0, 0);
             }
-            constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;      // LDS distance between consecutive output rows
-            const float* a_s = As + abuf * (BK * LDA) + aoff + l31;
-            const float* b_s = Bs + (step & 1) * (BK * LDB) + wn0 + l31;
+            if (R16) {      // 16-column remainder: lane (row/col = l&15, kq = l>>4) takes plane (kq&1)*2 + (kq>>1): 4 k per MFMA
+                const floatx4 bv = *reinterpret_cast<const floatx4*>(b16_lane + (step & 1) * BCH);
 #pragma unroll
-            for (int s = 0; s < BK / 2; s++) {
-                const int k = 2 * s + h;
-                float a[WM], b[WN];
+                for (int sb = 0; sb < 2 * WM; sb++) {
+                    const floatx4 av16 = *reinterpret_cast<const floatx4*>(
+                        a16_lane + abuf * ACH + (aoff + (sb >> 1) * ROWSTEP + (sb & 1) * 16) * 4);
 #pragma unroll
-                for (int i = 0; i < WM; i++) a[i] = a_s[k * LDA + i * ROWSTEP];
-#pragma unroll
-                for (int j = 0; j < WN; j++) b[j] = b_s[k * LDB + 32 * j];
-#pragma unroll
-                for (int i = 0; i < WM; i++)
-#pragma unroll
-                    for (int j = 0; j < WN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            if (R16) {      // 16-column remainder: A[row = l&15][k = l>>4], B[k = l>>4][col = l&15], four k per instruction
-                const float* a16 = As + abuf * (BK * LDA) + aoff + l15;
-                const float* b16 = Bs + (step & 1) * (BK * LDB) + wn0 + WN * 32 + l15;
-#pragma unroll
-                for (int s4 = 0; s4 < BK / 4; s4++) {
-                    const int k = 4 * s4 + kq;
-                    const float bv = b16[k * LDB];
-#pragma unroll
-                    for (int sb = 0; sb < 2 * WM; sb++) {
-                        const float av16 = a16[k * LDA + (sb >> 1) * ROWSTEP + (sb & 1) * 16];
-                        acc16[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av16, bv, acc16[sb], 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; e++)
+                        acc16[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av16[e], bv[e], acc16[sb], 0, 0, 0);
                 }
             }
-#ifndef RNR_ABLATE_NOLOAD
+#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
             if (ABUFS == 2) {
 #pragma unroll
                 for (int u = 0; u < APS; u++) {
@@ -808,7 +828,11 @@ pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restri
             v = w[((size_t)ci * d.c_out + co) * 16 + ky * 4 + kx];
         }
     }
-    packed[i] = v;
+    // destination: chunk-major plane image [par][tap][chunk][4 g][wstride][4 e], k = c % 16 -> g = 2*(k&1) + (k>>3),
+    // e = (k>>1)&3  (the LDS image conv_halo_kernel DMAs verbatim)
+    const int k = c & 15;
+    const long chunk = ((long)(par * taps + tp) * (ctot / 16) + (c >> 4));
+    packed[(chunk * 4 + (2 * (k & 1) + (k >> 3))) * ((long)wstride * 4) + (long)co * 4 + ((k >> 1) & 3)] = v;
 }
 
 struct ConvPlan {
@@ -843,6 +867,9 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     }
     const int th = p->bm / 32;
     p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
+    // the halo kernels address a view with 32-bit element offsets
+    const long view_elems = (long)H * W * (d->c_in0_pad > d->c_in1_pad ? d->c_in0_pad : d->c_in1_pad);
+    if (view_elems >= (1L << 30)) p->halo = 0;
     if (p->halo) {
         p->mtiles = N * (p->Ho / th) * (p->Wo / 32);
         if (p->cfg == 1) { p->bn = 80; p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn; }

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'librnr_hip.so')
+# RNR_HIP_LIB: load another build of the same library (kernel ablation experiments); default is the in-tree build
+LIB_PATH = os.environ.get('RNR_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'librnr_hip.so')
 
 c_void_p, c_int, c_float, c_size_t, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                                                 ctypes.c_double)
