@@ -71,17 +71,19 @@ def cpu_baseline(sc, args, view_id, hip_image):
         ctypes.CDLL('libgomp.so.1').omp_set_num_threads(cores)
     except OSError:
         pass
-    views = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [view_id]).items()}
     mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    n_frames = 2                                   # bounded sample: ~10 s of host work
     t0 = time.time()
-    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
-    lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]                   # network.py:622-627
-    ref = orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'],
-                           sc['pivots_diff'])
-    dt = time.time() - t0
+    for vid in [(view_id + 360) % 720, view_id][-n_frames:]:      # the LAST one is the frame the HIP path rendered last
+        views = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [vid]).items()}
+        basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+        lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]                   # network.py:622-627, per view
+        ref = orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'],
+                               sc['pivots_diff'])
+    dt = (time.time() - t0) / n_frames
     out = {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-           'sample': '1 frame %dx%d, same scene/weights (oracle: OpenMP C rasterizer + torch-CPU fp32 shading/U-Net), %.1f s'
-                     % (args.img_size, args.img_size, dt)}
+           'sample': '%d frames %dx%d, same scene/weights (oracle: OpenMP C rasterizer + torch-CPU fp32 shading/U-Net), %.1f s per frame'
+                     % (n_frames, args.img_size, args.img_size, dt)}
     parity = None
     if hip_image is not None:
         parity = {'psnr_db_vs_oracle': orc.psnr(hip_image.cpu(), ref['image']),
