@@ -103,6 +103,28 @@ int rnr_backward_depth_map(const float* faces, const float* depth_map, const int
                            const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
                            float* grad_faces, int batch_size, int num_faces, int image_size, void* stream);
 
+/*
+ * neural_renderer.cuda.load_textures.load_textures (load_textures_cuda.cpp:20-34 -> load_textures_cuda_kernel.cu:6-152):
+ * bake a texture image into the per-face texture cubes of the faces flagged in is_update.
+ *   image [ih, iw, 3]; faces [nf, 3, 2] uv per face corner, WRAPPED IN PLACE (REPEAT 0 / MIRRORED_REPEAT 1 /
+ *   CLAMP_TO_EDGE 2; CLAMP_TO_BORDER 3 leaves them and writes zero cubes); textures [nf, ts, ts, ts, 3] in/out;
+ *   is_update [nf] int32.  The reference re-wraps the coordinates from every texel thread (a race when a coordinate is
+ *   an exact integer); here each coordinate is wrapped once.
+ */
+int rnr_load_textures(const float* image, float* faces, float* textures, const int32_t* is_update, int num_faces,
+                      int texture_size, int image_height, int image_width, int texture_wrapping, int use_bilinear,
+                      void* stream);
+
+/*
+ * neural_renderer.cuda.create_texture_image.create_texture_image (create_texture_image_cuda.cpp:17-29 ->
+ * create_texture_image_cuda_kernel.cu:8-163): lay the face cubes out as tiles of a texture atlas.
+ *   vertices_all [nf, 3, 2] tile triangles in pixels (save_obj.py:10-24); textures [nf, tsi, tsi, tsi, 3];
+ *   image [image_height, image_width, 3], tile grid width = int(sqrt(nf - 1)) + 1, tile size = image_width / that.
+ *   Tiles beyond the last face are left as the caller filled them (the reference reads out of bounds there).
+ */
+int rnr_create_texture_image(const float* vertices_all, const float* textures, float* image, int num_faces,
+                             int texture_size_in, int image_height, int image_width, float eps, void* stream);
+
 /* =====================================================================================================
  * 2. Fused hot path (one view batch = N camera poses of one mesh)
  * ===================================================================================================== */

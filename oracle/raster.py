@@ -107,3 +107,20 @@ def backward_depth_map(faces, depth_map, fim, face_inv_map, weight_map, grad_dep
     dm, fim, fivm, wm, gd = _c(depth_map), _c(fim, np.int32), _c(face_inv_map), _c(weight_map), _c(grad_depth_map)
     lib().oracle_backward_depth_map(_p(faces), _p(dm), _p(fim), _p(fivm), _p(wm), _p(gd), _p(gf), B, nf, int(image_size))
     return gf
+
+
+def load_textures(image, faces_uv, textures, is_update, wrapping, use_bilinear):
+    """-> (textures, wrapped faces_uv); inputs are not modified."""
+    image, f, t = _c(image), _c(faces_uv).copy(), _c(textures).copy()
+    upd = _c(is_update, np.int32)
+    lib().oracle_load_textures(_p(image), _p(f), _p(t), _p(upd), f.shape[0], t.shape[1], image.shape[0], image.shape[1],
+                               int(wrapping), int(bool(use_bilinear)))
+    return t, f
+
+
+def create_texture_image(vertices_all, textures, image_hw, eps):
+    v, t = _c(vertices_all), _c(textures)
+    img = np.zeros((int(image_hw[0]), int(image_hw[1]), 3), np.float32)
+    lib().oracle_create_texture_image(_p(v), _p(t), _p(img), t.shape[0], t.shape[1], img.shape[0], img.shape[1],
+                                      ctypes.c_float(eps))
+    return img

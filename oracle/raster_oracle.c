@@ -315,3 +315,99 @@ void oracle_backward_depth_map(const float* faces, const float* depth_map, const
             for (int l = 0; l < 2; l++) g[3 * k + l] += -gd * t[l] * w[k] * d2 * (float)image_size / 2.0f;
     }
 }
+
+/* =====================================================================================================
+ * Texture-cube <-> image kernels (load_textures_cuda_kernel.cu:6-115, create_texture_image_cuda_kernel.cu:8-116).
+ * oracle_load_textures wraps each uv coordinate ONCE (the reference re-wraps in place from every texel thread:
+ * identical for non-integer coordinates, racy for exact integers).
+ * ===================================================================================================== */
+static float uv_mod(float x, float y) { return x > 0 ? fmodf(x, y) : y + fmodf(x, y); }
+
+void oracle_load_textures(const float* image, float* faces, float* textures, const int32_t* is_update, int num_faces,
+                          int ts, int ih, int iw, int wrapping, int use_bilinear) {
+    for (int c = 0; c < num_faces * 6; c++) {
+        if (!is_update[c / 6]) continue;
+        float f = faces[c];
+        if (wrapping == 0) f = uv_mod(f, 1.0f);
+        else if (wrapping == 1) f = uv_mod(f, 2.0f) < 1 ? uv_mod(f, 1.0f) : 1 - uv_mod(f, 1.0f);
+        else if (wrapping == 2) f = fmaxf(fminf(f, 1.0f), 0.0f);
+        faces[c] = f;
+    }
+    const long cube = (long)ts * ts * ts;
+    for (long i = 0; i < num_faces * cube; i++) {
+        const int fn = (int)(i / cube);
+        if (!is_update[fn]) continue;
+        float* t = textures + i * 3;
+        if (wrapping == 3) { t[0] = t[1] = t[2] = 0.0f; continue; }
+        float b[3] = {(float)((i / (ts * ts)) % ts) / (float)(ts - 1), (float)((i / ts) % ts) / (float)(ts - 1),
+                      (float)(i % ts) / (float)(ts - 1)};
+        if (0 < b[0] + b[1] + b[2]) {
+            const float s = b[0] + b[1] + b[2];
+            b[0] /= s; b[1] /= s; b[2] /= s;
+        }
+        const float* f = faces + (long)fn * 6;
+        const float px = (f[0] * b[0] + f[2] * b[1] + f[4] * b[2]) * (float)(iw - 1);
+        const float py = (f[1] * b[0] + f[3] * b[1] + f[5] * b[2]) * (float)(ih - 1);
+        if (use_bilinear) {
+            const int x0 = (int)px, y0 = (int)py;
+            int x1 = x0 + 1, y1 = (int)(py + 1);
+            if (x1 > iw - 1) x1 = iw - 1;
+            if (y1 > ih - 1) y1 = ih - 1;
+            const float wx1 = px - (float)x0, wx0 = 1 - wx1, wy1 = py - (float)y0, wy0 = 1 - wy1;
+            for (int k = 0; k < 3; k++) {
+                float c = 0;
+                c += image[((long)y0 * iw + x0) * 3 + k] * (wx0 * wy0);
+                c += image[((long)y1 * iw + x0) * 3 + k] * (wx0 * wy1);
+                c += image[((long)y0 * iw + x1) * 3 + k] * (wx1 * wy0);
+                c += image[((long)y1 * iw + x1) * 3 + k] * (wx1 * wy1);
+                t[k] = c;
+            }
+        } else {
+            const int xi = (int)roundf(px), yi = (int)roundf(py);
+            for (int k = 0; k < 3; k++) t[k] = image[((long)yi * iw + xi) * 3 + k];
+        }
+    }
+}
+
+void oracle_create_texture_image(const float* vertices_all, const float* textures, float* image, int num_faces, int tsi,
+                                 int image_height, int image_width, float eps) {
+    int tw = 1;
+    while ((long)tw * tw <= (long)num_faces - 1) tw++;
+    const int tso = image_width / tw;
+    for (int y = 0; y < image_height; y++)
+        for (int x = 0; x < image_width; x++) {
+            const int fn = x / tso + (y / tso) * tw;
+            if (fn >= num_faces) continue;              /* the reference reads out of bounds here */
+            const float* tex = textures + (long)fn * tsi * tsi * tsi * 3;
+            const float* p0 = vertices_all + (long)fn * 6; const float* p1 = p0 + 2; const float* p2 = p0 + 4;
+            float inv[9] = {p1[1] - p2[1], p2[0] - p1[0], p1[0] * p2[1] - p2[0] * p1[1],
+                            p2[1] - p0[1], p0[0] - p2[0], p2[0] * p0[1] - p0[0] * p2[1],
+                            p0[1] - p1[1], p1[0] - p0[0], p0[0] * p1[1] - p1[0] * p0[1]};
+            const float den = p2[0] * (p0[1] - p1[1]) + p0[0] * (p1[1] - p2[1]) + p1[0] * (p2[1] - p0[1]);
+            for (int k = 0; k < 9; k++) inv[k] /= den;
+            float w[3], ws = 0;
+            for (int k = 0; k < 3; k++) { w[k] = inv[3 * k] * (float)x + inv[3 * k + 1] * (float)y + inv[3 * k + 2]; ws += w[k]; }
+            float tf[3];
+            for (int k = 0; k < 3; k++) {
+                w[k] /= (ws + eps);
+                tf[k] = fminf(fmaxf(w[k] * (float)(tsi - 1), 0.0f), (float)(tsi - 1) - eps);
+            }
+            float px[3] = {0, 0, 0};
+            for (int pn = 0; pn < 8; pn++) {
+                float wt = 1; int ti[3];
+                for (int k = 0; k < 3; k++) {
+                    const int fl = (int)tf[k];
+                    if (((pn >> k) & 1) == 0) { wt *= 1 - (tf[k] - (float)fl); ti[k] = fl; }
+                    else { wt *= tf[k] - (float)fl; ti[k] = fl + 1; }
+                }
+                const int isc = ti[0] * tsi * tsi + ti[1] * tsi + ti[2];
+                for (int k = 0; k < 3; k++) px[k] += wt * tex[isc * 3 + k];
+            }
+            for (int k = 0; k < 3; k++) image[((long)y * image_width + x) * 3 + k] = px[k];
+        }
+    for (int y = 0; y < image_height; y++)
+        for (int x = 0; x < image_width; x++)
+            if ((y % tso + 1) == (x % tso))
+                for (int k = 0; k < 3; k++)
+                    image[((long)y * image_width + x) * 3 + k] = image[((long)y * image_width + x - 1) * 3 + k];
+}

@@ -4,11 +4,13 @@
 `nr.vertex_attrs_to_faces`, `nr.rasterize_rgbad`, `nr.Rasterize`, ...), backed by librnr_hip.so.
 
 The rasterizer is differentiable (RasterizeFunction: HIP backward kernels for the rgb/alpha/depth maps and textures).
-Out of scope (SURVEY.md §2.1): look / look_at / perspective camera modes, Mesh helper, save_obj, texture loading;
-those names raise NotImplementedError instead of silently misbehaving.
+Textured OBJ loading / saving (load_obj(load_texture=True), save_obj) run the load_textures / create_texture_image
+HIP kernels.  Out of scope: look / look_at / perspective camera modes and the Mesh helper; those names
+raise NotImplementedError instead of silently misbehaving.
 """
 from .lighting import lighting
 from .load_obj import load_obj
+from .save_obj import save_obj
 from .projection import projection
 from .rasterize import (rasterize_rgbad, rasterize, rasterize_silhouettes, rasterize_depth, Rasterize)
 from .renderer import Renderer
@@ -27,7 +29,6 @@ get_points_from_angles = _unsupported('get_points_from_angles')
 look = _unsupported('look')
 look_at = _unsupported('look_at')
 perspective = _unsupported('perspective')
-save_obj = _unsupported('save_obj')
 Mesh = _unsupported('Mesh')
 
 __version__ = '1.1.3+rnr_hip'

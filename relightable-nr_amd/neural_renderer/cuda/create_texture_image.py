@@ -1,5 +1,2 @@
-"""`neural_renderer.cuda.create_texture_image` — export utility of save_obj only; out of scope."""
-
-
-def create_texture_image(*a, **k):
-    raise NotImplementedError('create_texture_image (save_obj atlas baking) is out of scope of the hot-path build')
+"""`neural_renderer.cuda.create_texture_image` (reference: create_texture_image_cuda.cpp:17-33) on the HIP kernels."""
+from rnr_amd.ops import create_texture_image  # noqa: F401

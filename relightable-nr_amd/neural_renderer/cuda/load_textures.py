@@ -1,5 +1,2 @@
-"""`neural_renderer.cuda.load_textures` — never reached on the hot path (network.py:108 uses load_texture=False)."""
-
-
-def load_textures(*a, **k):
-    raise NotImplementedError('load_textures (OBJ-with-texture baking) is out of scope of the hot-path build')
+"""`neural_renderer.cuda.load_textures` (reference: load_textures_cuda.cpp:20-38) on the HIP kernel of librnr_hip.so."""
+from rnr_amd.ops import load_textures  # noqa: F401

@@ -55,6 +55,8 @@ SIGNATURES = {
     'rnr_backward_pixel_map': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     'rnr_backward_textures': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
     'rnr_backward_depth_map': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    'rnr_load_textures': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    'rnr_create_texture_image': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p]),
     'rnr_project_vertices': (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_void_p]),
     'rnr_gbuffer_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'rnr_rasterize_gbuffer': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_float, P(RnrGbuffer),

@@ -114,6 +114,26 @@ def backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_ma
     return grad_faces
 
 
+def load_textures(image, faces, textures, is_update, texture_wrapping, use_bilinear):
+    """load_textures_cuda.cpp:20-34.  `faces` [nf,3,2] uv are wrapped in place, `textures` [nf,ts,ts,ts,3] updated in
+    place for the faces flagged in is_update [nf] int32; returns textures."""
+    L = _lib.load()
+    _chk(image, 'image'); _chk(faces, 'faces'); _chk(textures, 'textures'); _chk(is_update, 'is_update', torch.int32)
+    check(L.rnr_load_textures(_ptr(image), _ptr(faces), _ptr(textures), _ptr(is_update), textures.shape[0],
+                              textures.shape[1], image.shape[0], image.shape[1], int(texture_wrapping),
+                              int(bool(use_bilinear)), _stream()))
+    return textures
+
+
+def create_texture_image(vertices_all, textures, image, eps):
+    """create_texture_image_cuda.cpp:17-29.  Fills `image` [H,W,3] in place and returns it."""
+    L = _lib.load()
+    _chk(vertices_all, 'vertices_all'); _chk(textures, 'textures'); _chk(image, 'image')
+    check(L.rnr_create_texture_image(_ptr(vertices_all), _ptr(textures), _ptr(image), textures.shape[0],
+                                     textures.shape[1], image.shape[0], image.shape[1], float(eps), _stream()))
+    return image
+
+
 # ---------------------------------------------------------------------------------------------------
 # fused path
 # ---------------------------------------------------------------------------------------------------

@@ -64,6 +64,23 @@ def test_raster_backward_c_bit_exact(golden, name):
     assert np.abs(g['grad_faces_pixel_both']).max() > 1 and np.abs(g['grad_faces_depth']).max() > 1      # not vacuous
 
 
+def test_texture_kernels_c_bit_exact(golden):
+    """load_textures / create_texture_image restatements vs the reference kernels' outputs (serial shim run)."""
+    from oracle import raster as oras
+    g = golden('load_textures40')
+    for w in range(4):
+        for b in (1, 0):
+            t, f = oras.load_textures(g['image'], g['faces_uv'], g['textures_in'], g['is_update'], w, b)
+            assert np.array_equal(t, g['textures_w%d_b%d' % (w, b)]), (w, b)
+            assert np.array_equal(f, g['faces_w%d' % w]), w
+    skipped = g['is_update'] == 0
+    assert skipped.any() and np.all(g['textures_w0_b1'][skipped] == 0.5)          # untouched faces keep their cubes
+    g = golden('create_texture_image')
+    for tag in 'ab':
+        img = oras.create_texture_image(g['vertices_' + tag], g['textures_' + tag], g['image_' + tag].shape[:2], float(g['eps']))
+        assert np.array_equal(img, g['image_' + tag]), tag
+
+
 def test_projection(golden):
     g = golden('projection')
     a = orc.projection(T(g['vertices']), T(g['K']), T(g['R']), T(g['t']), torch.zeros(1, 5), int(g['orig_size']))
