@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--tex-ch', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--main-loop-only', action='store_true',
+                    help='skip the per-stage and single-view extras after the timed loop (rocprofv3 runs: every kernel launch in the profile then belongs to a timed or warm-up step)')
     return ap.parse_args()
 
 
@@ -179,6 +181,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pipe.unet.forward = orig_forward
+    last_frame = img[V - 1:V].clone()       # the frame buffers are reused by the extra renders below
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -207,6 +210,7 @@ def main():
                          'traffic_source': traffic_src,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms},
         }
+        extras = not args.main_loop_only
         # per-stage HIP events (5 extra steps outside the timed region): the non-conv stages against the HBM roofline
         P_px = args.img_size * args.img_size
         m = sc['mesh']
@@ -218,7 +222,7 @@ def main():
             'ray_render': 4 * 3 * sc['n_rays'] * P_px + 4 * (3 * sc['n_rays'] + 6) * P_px + 4 * P_px + 12 * P_px,
         }
         acc = {}
-        n_prof = 5
+        n_prof = 5 if extras else 0
         for s in range(n_prof):
             evs = []
             lo = (s % (args.steps + args.warmup)) * world * V
@@ -227,11 +231,12 @@ def main():
             torch.cuda.synchronize()
             for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
                 acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1) / n_prof
-        res['stages'] = {k: {'ms_per_step': acc[k],
+        if extras:
+            res['stages'] = {k: {'ms_per_step': acc[k],
                              **({'alg_bytes_per_step': alg[k] * V, 'GB/s': alg[k] * V / (acc[k] * 1e-3) / 1e9,
                                  'frac_of_hbm_peak': alg[k] * V / (acc[k] * 1e-3) / 1e9 / PEAK_HBM_GBS} if k in alg else {})}
                          for k in acc}
-        if world == 1 and V > 1:
+        if world == 1 and V > 1 and extras:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
             def one(s):
@@ -250,7 +255,7 @@ def main():
             res['single_view_mode'] = {'views_per_step': 1, 'ms_per_frame': dt1 * 1e3, 'frames_per_s': 1.0 / dt1}
         if not args.no_cpu_baseline and world == 1:
             last_id = int(ids[(args.warmup + args.steps - 1) * V + V - 1])
-            hip_last = None if args.no_parity else img[V - 1:V]
+            hip_last = None if args.no_parity else last_frame
             cb, parity = cpu_baseline(sc, args, last_id, hip_last)
             res['cpu_baseline'] = cb
             if parity:

@@ -1,14 +1,24 @@
-"""Merge rocprofv3 --pmc passes (counter_collection.csv) into per-kernel totals: {kernel: {counter: total, dispatches}}."""
+"""Merge rocprofv3 --pmc passes (one directory per pass under OUT/p*/) into per-kernel figures:
+{kernel: {COUNTER_total, COUNTER_per_dispatch, dispatches}} -> OUT/merged.json (the format of profiles/r*_pmc_per_kernel_*.json
+that bench.py reads for roofline.traffic)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 out = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(float))
-disp = defaultdict(set)
+disp = defaultdict(lambda: defaultdict(set))
 for f in glob.glob(os.path.join(out, 'p*', '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
-        acc[k][r['Counter_Name']] += float(r['Counter_Value'])
-        disp[k].add(r['Dispatch_Id'])
-res = {k: dict(v, dispatches=len(disp[k])) for k, v in acc.items()}
+        k, c = r['Kernel_Name'], r['Counter_Name']
+        acc[k][c] += float(r['Counter_Value'])
+        disp[k][c].add(r['Dispatch_Id'])
+res = {}
+for k, v in acc.items():
+    e = {}
+    for c, tot in v.items():
+        n = max(1, len(disp[k][c]))
+        e[c + '_total'] = tot
+        e[c + '_per_dispatch'] = tot / n
+        e['dispatches'] = n
+    res[k] = e
 json.dump(res, open(os.path.join(out, 'merged.json'), 'w'), indent=1, sort_keys=True)
 print('kernels', len(res))
