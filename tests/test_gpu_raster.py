@@ -116,6 +116,23 @@ def test_sphere_512_vs_oracle():
     assert 0.4 < cov < 0.7
 
 
+def test_dense_mesh_subpixel_faces_vs_oracle():
+    """409 600 faces at 256^2: faces far smaller than a pixel, > 1000 candidates per 16x16 tile and list overflow at the
+    poles (the scan fallback) in the same image; batch of two views.  Still bit-exact."""
+    from oracle import raster as oras
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    mesh = scene.uv_sphere(320, 640)
+    assert mesh['f_v_idx'].shape[0] == 409600
+    v = scene.spiral_views(256, [0, 250])
+    uvz = orc.projection(torch.from_numpy(mesh['v'])[None], torch.from_numpy(v['proj']), torch.from_numpy(v['pose'][:, :3, :3]),
+                         torch.from_numpy(v['pose'][:, :3, 3])[:, None, :], torch.zeros(2, 5), 256)
+    faces = orc.gather_faces(uvz, torch.from_numpy(mesh['f_v_idx'])[None]).numpy()
+    g = oras.face_index_map(faces, 256, 0.0, 1e5)
+    r = run_hip_raster(faces, 256, 0.0, 1e5)
+    assert_same(r, g)
+
+
 def test_texture_sampling_golden(golden):
     from rnr_amd import ops
     g = golden('raster_texsample32')
