@@ -11,6 +11,7 @@ N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --mas
              frames are all-gathered over RCCL each step — the only collective of the path)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -39,6 +40,10 @@ def parse():
     ap.add_argument('--tex-ch', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--tile-skip', action='store_true',
+                    help='let the out layer skip all-background pixel tiles in the timed loop (frames are bit-identical; '
+                         'off by default so that `value` is the full RenderingNet on every pixel; the skip-enabled rate '
+                         'is reported beside it as with_background_tile_skip)')
     ap.add_argument('--main-loop-only', action='store_true',
                     help='skip the per-stage and single-view extras after the timed loop (rocprofv3 runs: every kernel launch in the profile then belongs to a timed or warm-up step)')
     return ap.parse_args()
@@ -129,7 +134,8 @@ def main():
     sc = build_scene(args)
     V = args.views_per_step
     pipe = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'],
-                       None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10)
+                       None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10,
+                       skip_background_tiles=args.tile_skip)
     # pose slices: step s, rank r renders spiral views (s*world + r)*V ... +V  (mod 720)
     n_total = (args.steps + args.warmup) * world * V
     ids = (np.arange(n_total) * 7) % 720
@@ -161,10 +167,16 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
     orig_forward = pipe.unet.forward
 
-    def timed_forward(net_in, n_views=None, _i=[0]):
+    active_tiles = torch.zeros(1, dtype=torch.int64, device=dev)     # out-layer pixel tiles actually computed
+    out_step = pipe.unet.steps[-1]
+    out_tiles_per_step = pipe.unet.L.rnr_conv_tile_count(ctypes.byref(out_step['desc']), V, args.img_size, args.img_size)
+
+    def timed_forward(net_in, n_views=None, consumer_alpha=None, _i=[0]):
         ev[2 * _i[0]].record()
-        r = orig_forward(net_in, n_views)
+        r = orig_forward(net_in, n_views, consumer_alpha)
         ev[2 * _i[0] + 1].record()
+        if consumer_alpha is not None and out_tiles_per_step:
+            active_tiles.add_(pipe.unet._tile_mask[:out_tiles_per_step].sum())
         _i[0] += 1
         return r
     pipe.unet.forward = timed_forward
@@ -187,7 +199,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     unet_ms = float(np.mean([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)]))
-    flops_step = pipe.unet.flops_per_view * V
+    # executed FLOPs: the live U-Net minus the out-layer tiles skipped because no pixel of them is ever read
+    d_out, (oh, ow) = out_step['desc'], out_step['in_hw']
+    out_flops_view = 2 * oh * ow * 9 * (d_out.c_in0 + d_out.c_in1) * d_out.c_out
+    skipped = 0.0
+    if args.tile_skip and out_tiles_per_step:
+        skipped = 1.0 - float(active_tiles.item()) / (out_tiles_per_step * args.steps)
+    flops_step = (pipe.unet.flops_per_view - skipped * out_flops_view) * V
     n_conv = len(pipe.unet.steps)
     achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
 
@@ -208,7 +226,11 @@ def main():
                          'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/step (HBM-side, PMC)',
                          'traffic_source': traffic_src,
-                         'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms},
+                         'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
+                         'out_layer_tiles_skipped': skipped,
+                         'flops_note': 'executed FLOPs = %.1f GFLOP/view live U-Net minus the out-layer pixel tiles that hold no '
+                                       'foreground pixel when --tile-skip is given (never read: the ray renderer zeroes background)'
+                                       % (pipe.unet.flops_per_view / 1e9)},
         }
         extras = not args.main_loop_only
         # per-stage HIP events (5 extra steps outside the timed region): the non-conv stages against the HBM roofline
@@ -236,6 +258,24 @@ def main():
                              **({'alg_bytes_per_step': alg[k] * V, 'GB/s': alg[k] * V / (acc[k] * 1e-3) / 1e9,
                                  'frac_of_hbm_peak': alg[k] * V / (acc[k] * 1e-3) / 1e9 / PEAK_HBM_GBS} if k in alg else {})}
                          for k in acc}
+        if extras and world == 1 and not args.tile_skip and out_tiles_per_step:
+            # product default of RNRPipeline: out-layer pixel tiles without a foreground pixel are not computed
+            pipe.skip_background_tiles = True
+            for s in range(2):
+                step(s)
+            drain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(args.warmup, args.warmup + args.steps):
+                step(s)
+            drain()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            frac = float(pipe.unet._tile_mask[:out_tiles_per_step].float().mean().item())
+            res['with_background_tile_skip'] = {'frames_per_s': args.steps * V / dts, 'ms_per_step': dts / args.steps * 1e3,
+                                                'active_out_layer_tiles_last_step': frac,
+                                                'note': 'bit-identical frames; not the headline value'}
+            pipe.skip_background_tiles = False
         if world == 1 and V > 1 and extras:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
@@ -265,7 +305,6 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        import ctypes
         ctypes.CDLL(None).fflush(None)     # RCCL's banner sits in C stdio's buffer when stdout is a pipe
         print(json.dumps(res), flush=True)
 

@@ -255,6 +255,23 @@ int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_
                const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h, int in_w,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Output-tile masking for a convolution whose output is consumed only where a mask is set — the out layer of
+ * RenderingNet: the ray renderer zeroes every background pixel (rays_uv = -1 there, network.py:469-470, 497), so the
+ * out-layer activations of all-background pixel tiles are never read.
+ *   rnr_conv_tile_count   number of pixel tiles rnr_conv2d launches for (desc, N, H, W); 0 if that convolution cannot
+ *                         be masked (only 3x3 convolutions on the LDS-halo plan without split-K can);
+ *   rnr_conv_active_tiles tile_mask[t] = 1 iff any alpha [N,H,W] > 0 inside tile t;
+ *   rnr_conv2d_masked     rnr_conv2d that leaves out_raw of tiles with tile_mask[t] == 0 untouched.  stats must be NULL
+ *                         (batch statistics need every pixel).  tile_mask == NULL is rnr_conv2d.
+ */
+size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int in_h, int in_w);
+int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha, uint8_t* tile_mask, int num_views, int in_h,
+                          int in_w, void* stream);
+int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                      const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h, int in_w,
+                      void* workspace, size_t workspace_bytes, const uint8_t* tile_mask, void* stream);
+
 /* stats [N,c_pad,2] (sum, sumsq over `count` pixels) + gamma/beta [channels] -> scale/shift [N,c_pad]:
  * scale = gamma / sqrt(var_biased + eps), shift = beta - mean * scale  (BatchNorm2d in train mode: per-view
  * batch statistics, biased variance); channels >= `channels` get scale = shift = 0. */

@@ -51,6 +51,7 @@ struct ConvParams {
     int splitk;
     long slab_stride;   // floats between split-K slabs
     int mtiles, ntiles, zdim;   // logical grid; the launch is 1-D and remapped per XCD (see tile_coords)
+    const uint8_t* tile_mask;   // optional [mtiles]: 0 = nobody reads this pixel tile's output, skip it (halo kernels)
 };
 
 // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only), and each XCD has a
@@ -405,6 +406,7 @@ conv_halo_kernel(const ConvParams P) {
     const int l15 = lane & 15, kq = lane >> 4;
     int mt_, nt_, z_;
     tile_coords(P, mt_, nt_, z_);
+    if (P.tile_mask && P.tile_mask[mt_] == 0) return;       // workgroup-uniform, before any barrier
     const int par = (KIND == 2) ? (z_ & 3) : 0;
     const int split = (KIND == 2) ? (z_ >> 2) : z_;
     const int py = par >> 1, px = par & 1;
@@ -835,6 +837,21 @@ pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restri
     packed[(chunk * 4 + (2 * (k & 1) + (k >> 3))) * ((long)wstride * 4) + (long)co * 4 + ((k >> 1) & 3)] = v;
 }
 
+// mask[tile] = any(alpha > 0) over the 32 x th output pixels of the tile (tile order = the halo kernels' mt index)
+__global__ void __launch_bounds__(256) active_tile_kernel(const float* __restrict__ alpha, uint8_t* __restrict__ mask, int H,
+                                                          int W, int th) {
+    const int tiles_x = W / 32, tiles_y = H / th;
+    const int mt = blockIdx.x;
+    const int n = mt / (tiles_x * tiles_y);
+    const int trem = mt - n * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * th, x0 = (trem % tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    int any = 0;
+    for (int y = ty; y < th; y += 8) any |= alpha[((size_t)n * H + y0 + y) * W + x0 + tx] > 0.f ? 1 : 0;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) mask[mt] = any ? 1 : 0;
+}
+
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
     int cfg;        // 0: 256x64, 1: 256x96, 2: 128x128
@@ -944,9 +961,37 @@ extern "C" size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views
     return (size_t)pl.splitk * num_views * pl.OH * pl.OW * d->c_out_pad * sizeof(float) + 256;
 }
 
+extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
+    if (!d || num_views <= 0 || d->kind != RNR_CONV3x3_REFLECT) return 0;
+    ConvPlan pl;
+    make_plan(d, num_views, in_h, in_w, &pl);
+    return (pl.halo && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
+}
+
+extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha, uint8_t* tile_mask, int num_views,
+                                     int in_h, int in_w, void* stream) {
+    if (int e = check_desc(d, "rnr_conv_active_tiles")) return e;
+    RNR_REQUIRE(alpha && tile_mask, "rnr_conv_active_tiles: null pointer argument");
+    RNR_REQUIRE(rnr_conv_tile_count(d, num_views, in_h, in_w) > 0,
+                "rnr_conv_active_tiles: this convolution does not run on maskable pixel tiles (3x3 halo plan without split-K)");
+    ConvPlan pl;
+    make_plan(d, num_views, in_h, in_w, &pl);
+    hipLaunchKernelGGL(active_tile_kernel, dim3((unsigned)pl.mtiles), dim3(256), 0, as_stream(stream), alpha, tile_mask,
+                       in_h, in_w, pl.bm / 32);
+    return check_launch("active_tile_kernel");
+}
+
 extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
                           const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
                           int in_w, void* workspace, size_t workspace_bytes, void* stream) {
+    return rnr_conv2d_masked(d, src0, src1, weight_packed, out_raw, stats, num_views, in_h, in_w, workspace,
+                             workspace_bytes, nullptr, stream);
+}
+
+extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                                 const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
+                                 int in_w, void* workspace, size_t workspace_bytes, const uint8_t* tile_mask,
+                                 void* stream) {
     if (int e = check_desc(d, "rnr_conv2d")) return e;
     RNR_REQUIRE(src0 && src0->data && weight_packed && out_raw, "rnr_conv2d: null pointer argument");
     RNR_REQUIRE(src0->channels == d->c_in0_pad, "rnr_conv2d: src0 has %d channels, descriptor says %d",
@@ -974,6 +1019,12 @@ extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, cons
     P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
     P.splitk = pl.splitk;
     P.mtiles = pl.mtiles; P.ntiles = pl.ntiles; P.zdim = pl.splitk * pl.par;
+    if (tile_mask) {
+        RNR_REQUIRE(!stats, "rnr_conv2d_masked: skipped tiles would falsify the batch statistics (stats must be NULL)");
+        RNR_REQUIRE(rnr_conv_tile_count(d, num_views, in_h, in_w) > 0,
+                    "rnr_conv2d_masked: this convolution does not run on maskable pixel tiles");
+        P.tile_mask = tile_mask;
+    }
     const size_t out_floats = (size_t)num_views * pl.OH * pl.OW * d->c_out_pad;
     if (stats) RNR_HIP(hipMemsetAsync(stats, 0, (size_t)num_views * d->c_out_pad * 2 * sizeof(double), st));
     if (pl.splitk > 1) {

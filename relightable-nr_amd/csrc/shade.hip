@@ -407,6 +407,11 @@ ray_render_kernel(const RayParams P) {
             al[k] = P.alpha[pix];
         }
     }
+    // background pixels contribute exactly 0 whatever the network produced there (uv = -1 masks the env-map taps):
+    // do not let their raw values in, the out layer may have skipped those tiles (rnr_conv2d_masked) and left garbage
+#pragma unroll
+    for (int k = 0; k < RR_PIX; k++)
+        if (al[k] == 0.0f) { y0[k] = 0.f; y1[k] = 0.f; y2[k] = 0.f; }
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
     if (ray_live) { b0 = P.bias[3 * r + 0]; b1 = P.bias[3 * r + 1]; b2 = P.bias[3 * r + 2]; }
     Taps tp[RR_PIX];

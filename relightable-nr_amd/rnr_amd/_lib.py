@@ -70,6 +70,10 @@ SIGNATURES = {
     'rnr_conv_workspace_bytes': (c_size_t, [P(RnrConvDesc), c_int, c_int, c_int]),
     'rnr_conv2d': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
                            c_int, c_void_p, c_size_t, c_void_p]),
+    'rnr_conv_tile_count': (c_size_t, [P(RnrConvDesc), c_int, c_int, c_int]),
+    'rnr_conv_active_tiles': (c_int, [P(RnrConvDesc), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_conv2d_masked': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'rnr_bn_finalize': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rnr_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -17,7 +17,8 @@ from .unet import UNetPlan
 
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
-                 sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10):
+                 sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10,
+                 skip_background_tiles=True):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
@@ -29,6 +30,9 @@ class RNRPipeline:
             (like `lighting_model(lighting_idx, is_lp=True)` inside RayRenderer.forward, network.py:494-495)
         """
         self.dev = torch.device(device)
+        # the ray renderer outputs exactly 0 on background pixels whatever the U-Net produced there (network.py:469-470,
+        # 497): the out layer need not compute pixel tiles that contain no foreground pixel.  Frames are bit-identical.
+        self.skip_background_tiles = bool(skip_background_tiles)
         self.S = int(img_size)
         self.near, self.far = float(near), float(far)
         v = torch.as_tensor(mesh['v'], dtype=torch.float32)
@@ -104,7 +108,7 @@ class RNRPipeline:
                               self.pivots_spec, self.pivots_diff, self.sh_start_ch, c_pad=self.unet.in_c_pad,
                               net_in=self._net_in[:N])
         mark('shade_inputs')
-        raw = self.unet.forward(sh['net_in'], N)
+        raw = self.unet.forward(sh['net_in'], N, gb['alpha'] if self.skip_background_tiles else None)
         mark('unet')
         img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff,
                              albedo_diff_ch=0, albedo_spec_ch=3, image=self._images[self._flip][:N])

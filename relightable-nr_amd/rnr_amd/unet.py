@@ -48,6 +48,7 @@ class UNetPlan:
         has = lambda k: (prefix + k) in sd
         self.steps = []
         self.ws_bytes = 256
+        self._tile_mask = None
         self._keep = []
 
         def conv_step(kind, srcs, wkey, bn_key, bias_key, act, c_out):
@@ -140,8 +141,10 @@ class UNetPlan:
         return RnrConvSrc(a.data.data_ptr(), a.scale.data_ptr() if a.scale is not None else None,
                           a.shift.data_ptr() if a.shift is not None else None, a.c_pad, a.act)
 
-    def forward(self, net_in, n_views=None):
-        """net_in [n,H,W,in_c_pad] channel-last -> raw out-layer output [n,H,W,out_c_pad] (bias/tanh NOT applied)."""
+    def forward(self, net_in, n_views=None, consumer_alpha=None):
+        """net_in [n,H,W,in_c_pad] channel-last -> raw out-layer output [n,H,W,out_c_pad] (bias/tanh NOT applied).
+        consumer_alpha [n,H,W]: promise that the caller reads the result only where alpha > 0 (the ray renderer zeroes
+        background pixels); the out layer then skips pixel tiles without any such pixel and leaves them unwritten."""
         n = net_in.shape[0] if n_views is None else n_views
         if n > self.N:
             raise RuntimeError('UNetPlan built for at most %d views, got %d' % (self.N, n))
@@ -150,15 +153,25 @@ class UNetPlan:
                                (tuple(net_in.shape), self.H, self.W, self.in_c_pad))
         self.input.data = net_in
         L, st = self.L, _stream()
+        last = self.steps[-1]
+        mask = None
+        if consumer_alpha is not None:
+            h, w = last['in_hw']
+            tiles = L.rnr_conv_tile_count(ctypes.byref(last['desc']), n, h, w)
+            if tiles and last['bn'] is None:
+                if self._tile_mask is None or self._tile_mask.numel() < tiles:
+                    self._tile_mask = torch.empty(tiles, dtype=torch.uint8, device=self.dev)
+                mask = self._tile_mask
+                check(L.rnr_conv_active_tiles(ctypes.byref(last['desc']), _ptr(consumer_alpha), _ptr(mask), n, h, w, st))
         for s in self.steps:
             srcs = s['srcs']
             s0 = self._src(srcs[0], n)
             s1 = self._src(srcs[1], n) if len(srcs) > 1 else None
             out, bn = s['out'], s['bn']
             h, w = s['in_hw']
-            check(L.rnr_conv2d(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
-                               _ptr(s['packed']), _ptr(out.data), _ptr(bn['stats']) if bn else None, n, h, w,
-                               _ptr(self.workspace), self.ws_bytes, st))
+            check(L.rnr_conv2d_masked(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
+                                      _ptr(s['packed']), _ptr(out.data), _ptr(bn['stats']) if bn else None, n, h, w,
+                                      _ptr(self.workspace), self.ws_bytes, _ptr(mask) if s is last else None, st))
             if bn:
                 check(L.rnr_bn_finalize(_ptr(bn['stats']), _ptr(bn['gamma']), _ptr(bn['beta']), _ptr(out.scale),
                                         _ptr(out.shift), n, out.c, out.c_pad, float(out.h * out.w), 1e-5, st))
