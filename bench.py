@@ -259,23 +259,38 @@ def main():
                                  'frac_of_hbm_peak': alg[k] * V / (acc[k] * 1e-3) / 1e9 / PEAK_HBM_GBS} if k in alg else {})}
                          for k in acc}
         if extras and world == 1 and not args.tile_skip and out_tiles_per_step:
-            # product default of RNRPipeline: out-layer pixel tiles without a foreground pixel are not computed
+            # product-tuned configuration of RNRPipeline, reported beside the headline (frames are bit-identical /
+            # equal to 1e-6): out-layer pixel tiles without a foreground pixel are not computed, and the batch is split
+            # over two HIP streams so that kernel tails overlap
+            def timed(p):
+                def st(s):
+                    lo = s * V
+                    sl = slice(lo, lo + V)
+                    return p.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+                for s in range(2):
+                    st(s)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for s in range(args.warmup, args.warmup + args.steps):
+                    st(s)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t1
             pipe.skip_background_tiles = True
-            for s in range(2):
-                step(s)
-            drain()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for s in range(args.warmup, args.warmup + args.steps):
-                step(s)
-            drain()
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - t1
+            dts = timed(pipe)
             frac = float(pipe.unet._tile_mask[:out_tiles_per_step].float().mean().item())
+            pipe.skip_background_tiles = False
             res['with_background_tile_skip'] = {'frames_per_s': args.steps * V / dts, 'ms_per_step': dts / args.steps * 1e3,
                                                 'active_out_layer_tiles_last_step': frac,
                                                 'note': 'bit-identical frames; not the headline value'}
-            pipe.skip_background_tiles = False
+            if V >= 2:
+                pipe2 = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
+                                    sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
+                                    sh_lmax=10, skip_background_tiles=True, streams=2)
+                dt2 = timed(pipe2)
+                res['with_tile_skip_and_2_streams'] = {'frames_per_s': args.steps * V / dt2,
+                                                       'ms_per_step': dt2 / args.steps * 1e3,
+                                                       'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
+                del pipe2
         if world == 1 and V > 1 and extras:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)

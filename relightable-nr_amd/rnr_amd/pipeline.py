@@ -18,7 +18,7 @@ from .unet import UNetPlan
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
                  sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10,
-                 skip_background_tiles=True):
+                 skip_background_tiles=True, streams=1):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
@@ -33,6 +33,9 @@ class RNRPipeline:
         # the ray renderer outputs exactly 0 on background pixels whatever the U-Net produced there (network.py:469-470,
         # 497): the out layer need not compute pixel tiles that contain no foreground pixel.  Frames are bit-identical.
         self.skip_background_tiles = bool(skip_background_tiles)
+        # streams > 1: a batch is split into that many view groups rendered on separate HIP streams, so that the tail of
+        # one group's kernel overlaps the next kernel of another group (+2 % at 8 views)
+        self.n_streams = max(1, int(streams))
         self.S = int(img_size)
         self.near, self.far = float(near), float(far)
         v = torch.as_tensor(mesh['v'], dtype=torch.float32)
@@ -51,8 +54,14 @@ class RNRPipeline:
         self.sh_start_ch = int(sh_start_ch)
         self.c_in = 3 * (self.n_spec + self.n_diff) + 6 + self.C
         self.max_views = int(max_views)
+        self.n_streams = min(self.n_streams, self.max_views)
+        lane_views = (self.max_views + self.n_streams - 1) // self.n_streams
         self.unet = UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
-                             (self.S, self.S), self.max_views, self.dev)
+                             (self.S, self.S), lane_views if self.n_streams > 1 else self.max_views, self.dev)
+        self._lane_unets = [self.unet] + [UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
+                                                   (self.S, self.S), lane_views, self.dev, share_weights_with=self.unet)
+                                          for _ in range(self.n_streams - 1)]
+        self._lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)] if self.n_streams > 1 else []
         self.sh_lighting, self.sh_coeff = None, None
         if sh_coeff is not None:
             from .lighting import SHLighting
@@ -68,8 +77,9 @@ class RNRPipeline:
         # two frame buffers: a caller that overlaps the all-gather of step k with the rendering of step k+1 alternates
         self._images = [torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self._flip = 0
-        self._ws = torch.empty(ops._lib.load().rnr_gbuffer_workspace_bytes(N, self.mesh.num_faces, S), dtype=torch.uint8,
-                               device=self.dev)
+        ws_views = N if self.n_streams == 1 else (N + self.n_streams - 1) // self.n_streams
+        self._lane_ws = [torch.empty(ops._lib.load().rnr_gbuffer_workspace_bytes(ws_views, self.mesh.num_faces, S),
+                                     dtype=torch.uint8, device=self.dev) for _ in range(self.n_streams)]
         for m in self._gb_maps:
             dt, tail = ops.GBUFFER_MAPS[m]
             self._gb[m] = torch.empty((N, S, S) + tail, dtype=dt, device=self.dev)
@@ -94,26 +104,53 @@ class RNRPipeline:
         N = proj.shape[0]
         if N > self.max_views:
             raise RuntimeError('pipeline built for max_views=%d, got %d poses' % (self.max_views, N))
-        proj, pose = proj.contiguous(), pose.contiguous()
-        R = pose[:, :3, :3].contiguous()
-        t = pose[:, :3, 3].contiguous()
-        v_uvz = ops.project_vertices(self.mesh.v, proj, R, t, self.S)
-        gb = {m: self._gb[m][:N] for m in self._gb_maps}
-        ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
-                              workspace=self._ws)
-        mark('raster')
+        proj, pose, proj_inv, R_inv = proj.contiguous(), pose.contiguous(), proj_inv.contiguous(), R_inv.contiguous()
         self.mesh._tangents = None          # per-face tangents recomputed per call, as get_TBN_map does (render.py:135-150)
+        self.mesh.tangents()
         lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
-        sh = ops.shade_inputs(gb, self.mesh, proj_inv.contiguous(), R_inv.contiguous(), self.textures,
-                              self.pivots_spec, self.pivots_diff, self.sh_start_ch, c_pad=self.unet.in_c_pad,
-                              net_in=self._net_in[:N])
-        mark('shade_inputs')
-        raw = self.unet.forward(sh['net_in'], N, gb['alpha'] if self.skip_background_tiles else None)
-        mark('unet')
-        img = ops.ray_render(raw, self.unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff,
-                             albedo_diff_ch=0, albedo_spec_ch=3, image=self._images[self._flip][:N])
-        mark('ray_render')
+        image = self._images[self._flip][:N]
         self._flip ^= 1
-        if keep_intermediates:
-            self.last = {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}
-        return img
+        lanes = 1 if (stage_events is not None or keep_intermediates) else min(self.n_streams, N)
+        if lanes == 1:
+            if N > self._lane_unets[0].N:
+                raise RuntimeError('pipeline built with streams=%d: a single-stream call takes at most %d poses'
+                                   % (self.n_streams, self._lane_unets[0].N))
+            inter = self._render_group(0, 0, N, proj, pose, proj_inv, R_inv, lp, image, mark)
+            if keep_intermediates:
+                self.last = inter
+            return image
+        # view groups on separate streams; shared per-call work (tangents, light probe) was issued on the caller's stream
+        cur = torch.cuda.current_stream()
+        per = (N + lanes - 1) // lanes
+        for i in range(lanes):
+            lo, hi = i * per, min(N, (i + 1) * per)
+            if lo >= hi:
+                break
+            st = self._lane_streams[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self._render_group(i, lo, hi, proj, pose, proj_inv, R_inv, lp, image, lambda name: None)
+        for st in self._lane_streams[:lanes]:
+            cur.wait_stream(st)
+        return image
+
+    def _render_group(self, lane, lo, hi, proj, pose, proj_inv, R_inv, lp, image, mark):
+        """Views [lo, hi) of the batch on the current stream, with lane-private scratch and U-Net activations."""
+        n = hi - lo
+        unet = self._lane_unets[lane]
+        R = pose[lo:hi, :3, :3].contiguous()
+        t = pose[lo:hi, :3, 3].contiguous()
+        v_uvz = ops.project_vertices(self.mesh.v, proj[lo:hi], R, t, self.S)
+        gb = {m: self._gb[m][lo:hi] for m in self._gb_maps}
+        ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
+                              workspace=self._lane_ws[lane])
+        mark('raster')
+        sh = ops.shade_inputs(gb, self.mesh, proj_inv[lo:hi], R_inv[lo:hi], self.textures, self.pivots_spec,
+                              self.pivots_diff, self.sh_start_ch, c_pad=unet.in_c_pad, net_in=self._net_in[lo:hi])
+        mark('shade_inputs')
+        raw = unet.forward(sh['net_in'], n, gb['alpha'] if self.skip_background_tiles else None)
+        mark('unet')
+        ops.ray_render(raw, unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff, albedo_diff_ch=0,
+                       albedo_spec_ch=3, image=image[lo:hi])
+        mark('ray_render')
+        return {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}

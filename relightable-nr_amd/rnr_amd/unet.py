@@ -33,9 +33,11 @@ class _Act:
 
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
-                 prefix='net.', in_c_pad=None, bn_mode='batch'):
+                 prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None):
         """bn_mode 'batch': BatchNorm2d in train mode (per-view batch statistics, what test_rnr.py:229-233 forces);
-        'running': eval-mode BatchNorm from the running_mean / running_var buffers of the state-dict."""
+        'running': eval-mode BatchNorm from the running_mean / running_var buffers of the state-dict.
+        share_weights_with: another UNetPlan of the same network whose packed weights / BN parameters are reused
+        (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
         self.L = _lib.load()
         self.dev = device
         self.N = int(max_views)
@@ -56,9 +58,12 @@ class UNetPlan:
             s0 = srcs[0]
             s1 = srcs[1] if len(srcs) > 1 else None
             desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
-            w = g(wkey)
-            packed = torch.empty(self.L.rnr_packed_weight_floats(ctypes.byref(desc)), dtype=torch.float32, device=device)
-            check(self.L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(w), _ptr(packed), _stream()))
+            if share_weights_with is not None:
+                packed = share_weights_with.steps[len(self.steps)]['packed']
+            else:
+                w = g(wkey)
+                packed = torch.empty(self.L.rnr_packed_weight_floats(ctypes.byref(desc)), dtype=torch.float32, device=device)
+                check(self.L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(w), _ptr(packed), _stream()))
             if kind == CONV3x3_REFLECT:
                 oh, ow = s0.h, s0.w
             elif kind == CONV4x4S2_REFLECT:

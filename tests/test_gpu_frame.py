@@ -103,6 +103,29 @@ def test_background_tile_skip_is_invisible():
     assert not torch.isnan(raw[..., 0][alpha > 0]).any()           # every foreground pixel was computed
 
 
+def test_stream_lanes_match_single_stream():
+    """RNRPipeline(streams=2/3): view groups on separate HIP streams give the frames of the single-stream run (only the
+    fp64 statistics atomics may reorder); odd batch sizes and batches smaller than the lane count included."""
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    sc = testing.tiny_scene(img_size=128, nf0=8, tex_size=64, tex_ch=24, nlat=31, nlon=62, seed=5)
+    mk = lambda s: RNRPipeline(sc['mesh'], 128, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'],
+                               sc['lp'], nf0=8, max_views=5, device=DEV, streams=s)
+    views = {k: T(v).to(DEV) for k, v in scene.spiral_views(128, [3, 100, 222, 400, 650]).items()}
+    call = lambda p, n: p.render(views['proj'][:n], views['pose'][:n], views['proj_inv'][:n], views['R_inv'][:n]).clone()
+    one = mk(1)
+    for s in (2, 3):
+        lanes = mk(s)
+        for n in (5, 4, 1):
+            a, b = call(one, n), call(lanes, n)
+            assert (a - b).abs().max() < 2e-5, (s, n)       # split-K depth depends on the views per plan: fp32 sums reorder
+    # back-to-back calls reuse lane buffers: results must not depend on what an earlier call left behind
+    lanes = mk(2)
+    first = call(lanes, 5)
+    call(lanes, 3)
+    assert (call(lanes, 5) - first).abs().max() < 2e-5
+
+
 def test_all_background_view():
     """Camera looking away from the mesh: every pixel is background (face index -1 wraps to the last face with zero
     weights, uv = (0,0), rays_uv = -1, network.py:176-190, 469-470).  The frame must still match the oracle."""
