@@ -231,7 +231,10 @@ typedef struct rnr_conv_desc {
     int c_in0, c_in0_pad;     /* first source: live channels, channel stride */
     int c_in1, c_in1_pad;     /* second source of a skip concat (0, 0 if none) */
     int c_out, c_out_pad;     /* live output channels, channel stride of out_raw (multiple of 16) */
+    int flags;                /* RNR_CONV_* bits, 0 by default */
 } rnr_conv_desc;
+/* `stats` already holds zeros when rnr_conv2d is called (rnr_bn_finalize_reset left them so): skip the memset. */
+#define RNR_CONV_STATS_PREZEROED 1
 
 /* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
 size_t rnr_packed_weight_floats(const rnr_conv_desc* d);
@@ -276,6 +279,10 @@ int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
  * scale = gamma / sqrt(var_biased + eps), shift = beta - mean * scale  (BatchNorm2d in train mode: per-view
  * batch statistics, biased variance); channels >= `channels` get scale = shift = 0. */
 int rnr_bn_finalize(const double* stats, const float* gamma, const float* beta, float* scale, float* shift,
+                    int num_views, int channels, int c_pad, double count, float eps, void* stream);
+/* rnr_bn_finalize that also resets stats to zero once consumed, so that the next rnr_conv2d into the same statistics
+ * buffer can run with RNR_CONV_STATS_PREZEROED (no memset launch per layer). */
+int rnr_bn_finalize_reset(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
                     int num_views, int channels, int c_pad, double count, float eps, void* stream);
 
 /* Layout helpers for the drop-in RenderingNet.forward (NCHW in / NCHW out). */

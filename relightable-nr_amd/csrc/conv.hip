@@ -778,8 +778,9 @@ splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int spli
     }
 }
 
+template <bool RESET>
 __global__ void __launch_bounds__(256)
-bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+bn_finalize_kernel(double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                    float* __restrict__ scale, float* __restrict__ shift, int nviews, int channels, int c_pad,
                    double count, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -796,6 +797,7 @@ bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ g
     }
     scale[i] = sc;
     shift[i] = sh;
+    if (RESET) { stats[2 * (size_t)i + 0] = 0.0; stats[2 * (size_t)i + 1] = 0.0; }
 }
 
 __host__ __device__ __forceinline__ int weight_row_stride(int c_out_pad) { return (c_out_pad + 127) / 128 * 128; }
@@ -931,6 +933,7 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
                 "%s: c_in1 %d / pad %d", who, d->c_in1, d->c_in1_pad);
     RNR_REQUIRE(d->c_out > 0 && d->c_out_pad >= d->c_out && d->c_out_pad % BK == 0,
                 "%s: c_out %d / pad %d", who, d->c_out, d->c_out_pad);
+    RNR_REQUIRE((d->flags & ~RNR_CONV_STATS_PREZEROED) == 0, "%s: unknown flags 0x%x", who, d->flags);
     return 0;
 }
 
@@ -1026,7 +1029,8 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.tile_mask = tile_mask;
     }
     const size_t out_floats = (size_t)num_views * pl.OH * pl.OW * d->c_out_pad;
-    if (stats) RNR_HIP(hipMemsetAsync(stats, 0, (size_t)num_views * d->c_out_pad * 2 * sizeof(double), st));
+    if (stats && !(d->flags & RNR_CONV_STATS_PREZEROED))
+        RNR_HIP(hipMemsetAsync(stats, 0, (size_t)num_views * d->c_out_pad * 2 * sizeof(double), st));
     if (pl.splitk > 1) {
         RNR_REQUIRE(workspace && workspace_bytes >= (size_t)pl.splitk * out_floats * sizeof(float),
                     "rnr_conv2d: workspace too small (%zu < %zu)", workspace_bytes,
@@ -1054,13 +1058,28 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
     return 0;
 }
 
-extern "C" int rnr_bn_finalize(const double* stats, const float* gamma, const float* beta, float* scale,
-                               float* shift, int num_views, int channels, int c_pad, double count, float eps,
-                               void* stream) {
+static int bn_finalize_impl(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
+                            int num_views, int channels, int c_pad, double count, float eps, bool reset, void* stream) {
     RNR_REQUIRE(stats && gamma && beta && scale && shift, "rnr_bn_finalize: null pointer argument");
     RNR_REQUIRE(num_views > 0 && channels > 0 && c_pad >= channels && count > 0, "rnr_bn_finalize: bad sizes");
     const int total = num_views * c_pad;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), stats, gamma,
-                       beta, scale, shift, num_views, channels, c_pad, count, eps);
+    if (reset)
+        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), stats, gamma,
+                           beta, scale, shift, num_views, channels, c_pad, count, eps);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), stats, gamma,
+                           beta, scale, shift, num_views, channels, c_pad, count, eps);
     return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int rnr_bn_finalize(const double* stats, const float* gamma, const float* beta, float* scale,
+                               float* shift, int num_views, int channels, int c_pad, double count, float eps,
+                               void* stream) {
+    return bn_finalize_impl(const_cast<double*>(stats), gamma, beta, scale, shift, num_views, channels, c_pad, count, eps,
+                            false, stream);
+}
+
+extern "C" int rnr_bn_finalize_reset(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
+                                     int num_views, int channels, int c_pad, double count, float eps, void* stream) {
+    return bn_finalize_impl(stats, gamma, beta, scale, shift, num_views, channels, c_pad, count, eps, true, stream);
 }

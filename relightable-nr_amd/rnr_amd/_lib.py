@@ -37,10 +37,11 @@ class RnrConvSrc(ctypes.Structure):
 
 class RnrConvDesc(ctypes.Structure):
     _fields_ = [('kind', c_int), ('c_in0', c_int), ('c_in0_pad', c_int), ('c_in1', c_int), ('c_in1_pad', c_int),
-                ('c_out', c_int), ('c_out_pad', c_int)]
+                ('c_out', c_int), ('c_out_pad', c_int), ('flags', c_int)]
 
 
 ACT_NONE, ACT_LRELU02, ACT_RELU = 0, 1, 2
+CONV_STATS_PREZEROED = 1
 CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2 = 0, 1, 2
 
 P = ctypes.POINTER
@@ -75,6 +76,7 @@ SIGNATURES = {
     'rnr_conv2d_masked': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'rnr_bn_finalize': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
+    'rnr_bn_finalize_reset': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rnr_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rnr_ray_render': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -83,6 +83,8 @@ class UNetPlan:
                 gamma, beta = g(bn_key + '.weight'), g(bn_key + '.bias')
                 out.scale = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
                 out.shift = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
+                # statistics start at zero and every rnr_bn_finalize_reset leaves them at zero: no memset per layer
+                desc.flags = _lib.CONV_STATS_PREZEROED
                 step['bn'] = {'gamma': gamma, 'beta': beta,
                               'stats': torch.zeros(self.N, desc.c_out_pad, 2, dtype=torch.float64, device=device)}
             elif bias_key is not None and has(bias_key):
@@ -168,6 +170,17 @@ class UNetPlan:
                     self._tile_mask = torch.empty(tiles, dtype=torch.uint8, device=self.dev)
                 mask = self._tile_mask
                 check(L.rnr_conv_active_tiles(ctypes.byref(last['desc']), _ptr(consumer_alpha), _ptr(mask), n, h, w, st))
+        try:
+            self._run_steps(n, mask, L, st)
+        except Exception:
+            for s in self.steps:            # a failed launch may leave statistics half-accumulated: restore the invariant
+                if s['bn']:
+                    s['bn']['stats'].zero_()
+            raise
+        return self.out.data[:n]
+
+    def _run_steps(self, n, mask, L, st):
+        last = self.steps[-1]
         for s in self.steps:
             srcs = s['srcs']
             s0 = self._src(srcs[0], n)
@@ -178,6 +191,6 @@ class UNetPlan:
                                       _ptr(s['packed']), _ptr(out.data), _ptr(bn['stats']) if bn else None, n, h, w,
                                       _ptr(self.workspace), self.ws_bytes, _ptr(mask) if s is last else None, st))
             if bn:
-                check(L.rnr_bn_finalize(_ptr(bn['stats']), _ptr(bn['gamma']), _ptr(bn['beta']), _ptr(out.scale),
+                check(L.rnr_bn_finalize_reset(_ptr(bn['stats']), _ptr(bn['gamma']), _ptr(bn['beta']), _ptr(out.scale),
                                         _ptr(out.shift), n, out.c, out.c_pad, float(out.h * out.w), 1e-5, st))
         return self.out.data[:n]
