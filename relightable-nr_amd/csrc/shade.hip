@@ -331,7 +331,7 @@ shade_inputs_kernel(const ShadeParams P) {
 __device__ __forceinline__ float fast_atan2f(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const float a = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;      // 1 ulp reciprocal: the result only picks env-map taps
     const float s = a * a;
     float p = 0.002899040700867772f;
     p = p * s - 0.01637016236782074f;
@@ -357,8 +357,15 @@ __device__ __forceinline__ float fast_acosf(float x) {
     p = p * ax + 0.08893882483243942f;
     p = p * ax - 0.2145957499742508f;
     p = p * ax + 1.570796251296997f;
-    const float r = sqrtf(1.0f - ax) * p;
+    const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
     return x < 0.0f ? 3.14159265358979324f - r : r;
+}
+
+// tanh(x) = 1 - 2 / (e^{2x} + 1) on v_exp_f32 / v_rcp_f32: absolute error ~1e-7 (what matters for tanh + 1, the light
+// transport factor), exact limits at +-inf; ocml's tanhf costs ~25 instructions and this kernel is VALU-bound.
+__device__ __forceinline__ float fast_tanhf(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^{2x}
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 struct RayParams {
@@ -407,19 +414,14 @@ ray_render_kernel(const RayParams P) {
             al[k] = P.alpha[pix];
         }
     }
-    // background pixels contribute exactly 0 whatever the network produced there (uv = -1 masks the env-map taps):
-    // do not let their raw values in, the out layer may have skipped those tiles (rnr_conv2d_masked) and left garbage
-#pragma unroll
-    for (int k = 0; k < RR_PIX; k++)
-        if (al[k] == 0.0f) { y0[k] = 0.f; y1[k] = 0.f; y2[k] = 0.f; }
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
     if (ray_live) { b0 = P.bias[3 * r + 0]; b1 = P.bias[3 * r + 1]; b2 = P.bias[3 * r + 2]; }
     Taps tp[RR_PIX];
 #pragma unroll
     for (int k = 0; k < RR_PIX; k++) {
         // rays_uv (render.py:96-102; network.py:469-470)
-        float u = fast_atan2f(dz[k], dx[k]) * 0.5f / RNR_PI_F + 0.5f;
-        float v = fast_acosf(dy[k]) * 1.0f / RNR_PI_F;
+        float u = fast_atan2f(dz[k], dx[k]) * (0.5f / RNR_PI_F) + 0.5f;
+        float v = fast_acosf(dy[k]) * (1.0f / RNR_PI_F);
         const float bg = (al[k] == 0.0f) ? 1.0f : 0.0f;
         u = u * al[k] - bg;
         v = v * al[k] - bg;
@@ -442,9 +444,13 @@ ray_render_kernel(const RayParams P) {
             const float col1 = l00[1] * t.w00 + l10[1] * t.w10 + l01[1] * t.w01 + l11[1] * t.w11;
             const float col2 = l00[2] * t.w00 + l10[2] * t.w10 + l01[2] * t.w01 + l11[2] * t.w11;
             // network.py:253 tanh; test_rnr.py:359 (y*0.5+0.5)*2
-            c0[k] = (tanhf(y0[k] + b0) * 0.5f + 0.5f) * 2.0f * col0;
-            c1[k] = (tanhf(y1[k] + b1) * 0.5f + 0.5f) * 2.0f * col1;
-            c2[k] = (tanhf(y2[k] + b2) * 0.5f + 0.5f) * 2.0f * col2;
+            c0[k] = (fast_tanhf(y0[k] + b0) * 0.5f + 0.5f) * 2.0f * col0;
+            c1[k] = (fast_tanhf(y1[k] + b1) * 0.5f + 0.5f) * 2.0f * col1;
+            c2[k] = (fast_tanhf(y2[k] + b2) * 0.5f + 0.5f) * 2.0f * col2;
+            // background pixels contribute exactly 0 whatever the network produced there (col = 0 by the uv = -1
+            // mask); select rather than multiply: the out layer may have skipped the tile (rnr_conv2d_masked) and
+            // left non-finite garbage.  Done here, after every load has landed, so the loads stay independent.
+            if (al[k] == 0.0f) { c0[k] = 0.f; c1[k] = 0.f; c2[k] = 0.f; }
         }
     }
 #pragma unroll
