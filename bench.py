@@ -44,6 +44,9 @@ def parse():
                     help='let the out layer skip all-background pixel tiles in the timed loop (frames are bit-identical; '
                          'off by default so that `value` is the full RenderingNet on every pixel; the skip-enabled rate '
                          'is reported beside it as with_background_tile_skip)')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
+                    help="conv arithmetic of the timed loop: exact fp32 MFMA (default, the headline) or fp32 emulated on the bf16 "
+                         "matrix cores (RNR_CONV_F32_EMU_BF16X6)")
     ap.add_argument('--main-loop-only', action='store_true',
                     help='skip the per-stage and single-view extras after the timed loop (rocprofv3 runs: every kernel launch in the profile then belongs to a timed or warm-up step)')
     return ap.parse_args()
@@ -135,7 +138,7 @@ def main():
     V = args.views_per_step
     pipe = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'],
                        None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10,
-                       skip_background_tiles=args.tile_skip)
+                       skip_background_tiles=args.tile_skip, precision=args.precision)
     # pose slices: step s, rank r renders spiral views (s*world + r)*V ... +V  (mod 720)
     n_total = (args.steps + args.warmup) * world * V
     ids = (np.arange(n_total) * 7) % 720

@@ -39,6 +39,7 @@ struct ConvParams {
     int src_c[2];
     int src_act[2];
     const float* weight;
+    const void* weight_emu;     // bf16x6 image of the same weights (conv_halo_emu_kernel), or NULL
     float* out;
     double* stats;
     int N, H, W;        // input spatial size
@@ -710,6 +711,300 @@ conv_halo_kernel(const ConvParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 emulation on the bf16 matrix cores ("bf16x6").
+//
+// A float is split exactly into three bf16 terms, x = h + m + l (8 + 8 + 8 mantissa bits, each the round-to-nearest
+// bf16 of the running remainder), and a product keeps the six partial products of weight >= 2^-16:
+//   a*b ~= ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm        (dropped: am*bl, al*bm, al*bl <= 2^-24 |a*b|)
+// Every partial product of two bf16 is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result
+// differs from the fp32 MFMA path only by terms of the size of fp32's own rounding (measured: tests/test_gpu_unet.py,
+// scripts/emu_accuracy.py) while one 16-channel chunk costs 6 x 32 = 192 MFMA cycles instead of 8 x 64 = 512.
+// Same tiling, halo staging, fused BatchNorm prologue / statistics epilogue as conv_halo_kernel (KIND 0 and 2 only).
+// LDS images of a 16-channel chunk: [3 terms][2 k-halves][X pixels or columns][8 bf16] — an MFMA lane (x, k-half)
+// reads its 8 channels of one term as one lane-consecutive ds_read_b128; the packed weights hold the same image.
+// One LDS copy of the halo; the next chunk's halo rides in registers across the taps (as the 4x4-s2 kernel does),
+// which keeps three workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// x = h + m + l exactly (for finite x away from the subnormal range); pairs of values -> packed bf16x2 words
+__device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const floatx2 v = {x0, x1};
+    const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+    const floatx2 r1 = v - __builtin_convertvector(hb, floatx2);
+    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+    const floatx2 r2 = r1 - __builtin_convertvector(mb, floatx2);
+    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hb); m = __builtin_bit_cast(unsigned, mb); l = __builtin_bit_cast(unsigned, lb);
+}
+
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(CTHREADS, WM * WN <= 4 ? RNR_HALO_WAVES : 2)
+conv_halo_emu_kernel(const ConvParams P) {
+    static_assert(KIND == 0 || KIND == 2, "3x3 and transposed 4x4-s2 convolutions");
+    static_assert(WAVES_M * WAVES_N == 4 && BK == 16, "four waves, 16-channel chunks");
+    constexpr int TW = 32, TH = WAVES_M * WM;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int TAPS = KIND == 0 ? 9 : 4;
+    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int ASLOTS = HP * 4;
+    constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
+    constexpr int APL = 2 * HP * 16, BPL = 2 * BN * 16;       // bytes per term plane (two k-halves)
+    constexpr int ACHB = 3 * APL, BCHB = 3 * BPL;             // bytes per chunk image
+    constexpr int RUNS = (BN + 63) / 64;
+    constexpr int NPB = 6 * RUNS;                             // DMA pieces per weight tile: (term, k-half, 64-column run)
+    constexpr int BPT = (NPB + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smemb[];
+    char* As = smemb;                   // [ACHB]
+    char* Bs = smemb + ACHB;            // [2][BCHB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int wn0 = wave_n * WN * 32;
+    int mt_, nt_, z_;
+    tile_coords(P, mt_, nt_, z_);
+    if (P.tile_mask && P.tile_mask[mt_] == 0) return;
+    const int par = (KIND == 2) ? (z_ & 3) : 0;
+    const int split = (KIND == 2) ? (z_ >> 2) : z_;
+    const int py = par >> 1, px = par & 1;
+    const int n0 = nt_ * BN;
+    const int tiles_x = P.Wo / TW, tiles_y = P.Ho / TH;
+    const int n = mt_ / (tiles_x * tiles_y);
+    const int trem = mt_ - n * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+
+    const int q = tid & 3;
+    unsigned spix[APT];
+    int sdst[APT];           // byte offset of this slot's 4 bf16 inside a term plane
+    float smask[KIND == 2 ? APT : 1];
+#pragma unroll
+    for (int j = 0; j < APT; j++) {
+        int s = tid + CTHREADS * j;
+        if (s >= ASLOTS) s -= ASLOTS;
+        const int hp = s >> 2;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        int iy, ix;
+        if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
+        else {
+            iy = y0 - 1 + hy; ix = x0 - 1 + hx;
+            const bool inside = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            smask[j] = inside ? 1.f : 0.f;
+            iy = min(max(iy, 0), P.H - 1); ix = min(max(ix, 0), P.W - 1);
+        }
+        sdst[j] = ((q >> 1) * HP + hp) * 16 + (q & 1) * 8;      // k-half = channels 8*(q>>1) .., 4 bf16 at (q&1)*4
+        spix[j] = (unsigned)(iy * P.W + ix);
+    }
+
+    const int nchunks = P.chunks_per_tap;
+    const int per_split = (nchunks + P.splitk - 1) / P.splitk;
+    const int c_begin = split * per_split;
+    const int c_end = min(nchunks, c_begin + per_split);
+
+    struct ChunkSrc { const float* base; unsigned C; int act; float4 sc, sh; };
+    auto chunk_src = [&](int c) {
+        ChunkSrc cs;
+        const int s = c < P.chunks0 ? 0 : 1;
+        const int cc = (c - (s ? P.chunks0 : 0)) * BK;
+        cs.C = (unsigned)P.src_c[s];
+        cs.base = P.src_data[s] + (size_t)n * P.H * P.W * cs.C + cc;
+        cs.act = P.src_act[s];
+        cs.sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        cs.sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.src_scale[s]) cs.sc = *reinterpret_cast<const float4*>(P.src_scale[s] + (size_t)n * cs.C + cc + 4 * q);
+        if (P.src_shift[s]) cs.sh = *reinterpret_cast<const float4*>(P.src_shift[s] + (size_t)n * cs.C + cc + 4 * q);
+        return cs;
+    };
+    auto load_a = [&](const ChunkSrc& cs, int j) {
+        const unsigned voff = spix[j] * cs.C + 4u * (unsigned)q;
+        return *reinterpret_cast<const float4*>(cs.base + voff);
+    };
+    auto store_a = [&](const ChunkSrc& cs, float4 v, int j) {
+        float x = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
+        float y = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
+        float z = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
+        float w = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
+        if (KIND == 2) { x *= smask[j]; y *= smask[j]; z *= smask[j]; w *= smask[j]; }
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_bf16x3(x, y, h0, m0, l0);
+        split_bf16x3(z, w, h1, m1, l1);
+        char* a = As + sdst[j];
+        *reinterpret_cast<uint2*>(a) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(a + APL) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(a + 2 * APL) = make_uint2(l0, l1);
+    };
+    // weight tile: packed image per (parity, tap, chunk) = [3 terms][2 k-halves][wstride][8 bf16]
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned bvoff[BPT];
+    int blds[BPT];
+    bool blive[BPT];
+#pragma unroll
+    for (int b = 0; b < BPT; b++) {
+        const int pc = wave_u + 4 * b;
+        const int g = pc / RUNS, run = pc - g * RUNS;           // g = term * 2 + k-half
+        bvoff[b] = ((unsigned)g * (unsigned)P.wstride + (unsigned)(n0 + 64 * run + lane)) * 16u;
+        blds[b] = (g * BN + 64 * run) * 16;
+        blive[b] = pc < NPB && (BN % 64 == 0 || lane < BN - 64 * run);     // 96-column tiles: 64 + 32 columns
+    }
+    const char* wemu = reinterpret_cast<const char*>(P.weight_emu);
+    auto dma_b = [&](int c, int t, int buf) {
+        const char* wt = wemu + ((size_t)(par * TAPS + t) * nchunks + c) * (96 * (size_t)P.wstride);
+#pragma unroll
+        for (int b = 0; b < BPT; b++) {
+            if ((NPB % 4 == 0 && BN % 64 == 0) || blive[b]) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + bvoff[b]),
+                                                 (__attribute__((address_space(3))) void*)(Bs + buf * BCHB + blds[b]),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    floatx16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+
+    const int wrow = wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const char* a_lane = As + (h * HP + wrow + l31) * 16;
+    const char* b_lane = Bs + (h * BN + wn0 + l31) * 16;
+
+    if (c_begin < c_end) {
+        const ChunkSrc cs = chunk_src(c_begin);
+#pragma unroll
+        for (int j = 0; j < APT; j++) store_a(cs, load_a(cs, j), j);
+        dma_b(c_begin, 0, 0);
+    }
+    __syncthreads();
+    int step = 0;
+    for (int c = c_begin; c < c_end; c++) {
+        const bool next_chunk = c + 1 < c_end;
+        ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
+        // the whole next halo is requested up front and parked in registers; the tap loop is NOT unrolled: unrolled, the
+        // scheduler hoists the LDS reads of later taps until the register file spills
+        float4 av_all[APT];
+        if (next_chunk) {
+#pragma unroll
+            for (int j = 0; j < APT; j++) av_all[j] = load_a(csn, j);
+        }
+#pragma unroll 1
+        for (int t = 0; t < TAPS; t++, step++) {
+            const bool more = next_chunk || t < TAPS - 1;
+            if (more) {
+                if (t < TAPS - 1) dma_b(c, t + 1, (step + 1) & 1); else dma_b(c + 1, 0, (step + 1) & 1);
+            }
+            int aoff;
+            if (KIND == 0) { const int ky = (t * 11) >> 5; aoff = ky * HWD + (t - 3 * ky); }      // t / 3 for t < 9
+            else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
+            const char* a_s = a_lane + aoff * 16;
+            const char* b_s = b_lane + (step & 1) * BCHB;
+            // all three weight terms stay live, the halo terms are fetched one at a time (l, m, h): 32 operand
+            // registers instead of 48; partial products still run smallest to largest per halo term
+            bf16x8 b[3][WN];
+#pragma unroll
+            for (int term = 0; term < 3; term++)
+#pragma unroll
+                for (int j = 0; j < WN; j++) b[term][j] = *reinterpret_cast<const bf16x8*>(b_s + term * BPL + 32 * j * 16);
+#pragma unroll
+            for (int ta = 2; ta >= 0; ta--) {
+                bf16x8 a[WM];
+#pragma unroll
+                for (int i = 0; i < WM; i++) a[i] = *reinterpret_cast<const bf16x8*>(a_s + ta * APL + i * HWD * 16);
+                // a_l pairs with b_h; a_m with b_m, b_h; a_h with b_l, b_m, b_h
+#pragma unroll
+                for (int tb = 2 - ta; tb >= 0; tb--)
+#pragma unroll
+                    for (int i = 0; i < WM; i++)
+#pragma unroll
+                        for (int j = 0; j < WN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[tb][j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        if (next_chunk) {       // every wave is past the last tap's reads: swap the next halo in
+#pragma unroll
+            for (int j = 0; j < APT; j++) store_a(csn, av_all[j], j);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (identical to conv_halo_kernel: same accumulator layout) ----
+    float* out = P.out + (size_t)split * P.slab_stride;
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+        const int y = y0 + wave_m * WM + i;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int x = x0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const size_t off = (KIND == 2)
+                ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
+                : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                const int col = n0 + wn0 + 32 * j + l31;
+                if (col < P.c_out_pad) out[off + col] = acc[i][j][g];
+            }
+        }
+    }
+    if (P.stats && P.splitk == 1) {
+        float* red = reinterpret_cast<float*>(As);   // [WAVES_M][BN][2]; LDS is free after the last barrier
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const float v = acc[i][j][g];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                const int col = wn0 + 32 * j + l31;
+                red[(wave_m * BN + col) * 2 + 0] = s1;
+                red[(wave_m * BN + col) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int col = n0 + tid;
+            if (col < P.c_out) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < WAVES_M; w++) {
+                    s1 += (double)red[(w * BN + tid) * 2 + 0];
+                    s2 += (double)red[(w * BN + tid) * 2 + 1];
+                }
+                double* st = P.stats + ((size_t)n * P.c_out_pad + col) * 2;
+                atomicAdd(st + 0, s1);
+                atomicAdd(st + 1, s2);
+            }
+        }
+    }
+}
+
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
+    constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32, HP = 34 * (TH + 2);
+    constexpr size_t lds = (size_t)(96 * HP + 2 * 96 * BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<KIND, WAVES_M, WAVES_N, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_halo_emu_kernel<KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
+}
+
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM, BN = WAVES_N * (WN * 32 + R16 * 16);
@@ -802,41 +1097,65 @@ bn_finalize_kernel(double* __restrict__ stats, const float* __restrict__ gamma, 
 
 __host__ __device__ __forceinline__ int weight_row_stride(int c_out_pad) { return (c_out_pad + 127) / 128 * 128; }
 
+// value of the (parity, tap, padded input channel c, output column co) entry of the implicit-GEMM weight matrix
+__device__ __forceinline__ float gemm_weight(const rnr_conv_desc& d, const float* __restrict__ w, int par, int tp, int c, int co) {
+    int ci = -1;
+    if (c < d.c_in0_pad) { if (c < d.c_in0) ci = c; }
+    else { const int c1 = c - d.c_in0_pad; if (c1 < d.c_in1) ci = d.c_in0 + c1; }
+    if (ci < 0 || co >= d.c_out) return 0.0f;
+    const int cin = d.c_in0 + d.c_in1;
+    if (d.kind == RNR_CONV3x3_REFLECT) return w[((size_t)co * cin + ci) * 9 + tp];
+    if (d.kind == RNR_CONV4x4S2_REFLECT) return w[((size_t)co * cin + ci) * 16 + tp];
+    const int py = par >> 1, px = par & 1, ty = tp >> 1, tx = tp & 1;
+    const int ky = py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
+    const int kx = px == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+    return w[((size_t)ci * d.c_out + co) * 16 + ky * 4 + kx];
+}
+
+// i enumerates [par][tap][c][co < wstride]
+__device__ __forceinline__ void gemm_weight_index(const rnr_conv_desc& d, long i, int& par, int& tp, int& c, int& co,
+                                                  int& taps, int& ctot, int& wstride) {
+    taps = d.kind == RNR_CONV3x3_REFLECT ? 9 : (d.kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
+    ctot = d.c_in0_pad + d.c_in1_pad;
+    wstride = weight_row_stride(d.c_out_pad);
+    co = (int)(i % wstride);
+    long r = i / wstride;
+    c = (int)(r % ctot);
+    r /= ctot;
+    tp = (int)(r % taps);
+    par = (int)(r / taps);
+}
+
 __global__ void __launch_bounds__(256)
 pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restrict__ packed, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int taps = d.kind == RNR_CONV3x3_REFLECT ? 9 : (d.kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
-    const int ctot = d.c_in0_pad + d.c_in1_pad;
-    const int wstride = weight_row_stride(d.c_out_pad);
-    const int co = (int)(i % wstride);
-    long r = i / wstride;
-    const int c = (int)(r % ctot);
-    r /= ctot;
-    const int tp = (int)(r % taps);
-    const int par = (int)(r / taps);
-    int ci = -1;
-    if (c < d.c_in0_pad) { if (c < d.c_in0) ci = c; }
-    else { const int c1 = c - d.c_in0_pad; if (c1 < d.c_in1) ci = d.c_in0 + c1; }
-    float v = 0.0f;
-    if (ci >= 0 && co < d.c_out) {
-        const int cin = d.c_in0 + d.c_in1;
-        if (d.kind == RNR_CONV3x3_REFLECT) {
-            v = w[((size_t)co * cin + ci) * 9 + tp];
-        } else if (d.kind == RNR_CONV4x4S2_REFLECT) {
-            v = w[((size_t)co * cin + ci) * 16 + tp];
-        } else {
-            const int py = par >> 1, px = par & 1, ty = tp >> 1, tx = tp & 1;
-            const int ky = py == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
-            const int kx = px == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
-            v = w[((size_t)ci * d.c_out + co) * 16 + ky * 4 + kx];
-        }
-    }
+    int par, tp, c, co, taps, ctot, wstride;
+    gemm_weight_index(d, i, par, tp, c, co, taps, ctot, wstride);
+    const float v = gemm_weight(d, w, par, tp, c, co);
     // destination: chunk-major plane image [par][tap][chunk][4 g][wstride][4 e], k = c % 16 -> g = 2*(k&1) + (k>>3),
     // e = (k>>1)&3  (the LDS image conv_halo_kernel DMAs verbatim)
     const int k = c & 15;
     const long chunk = ((long)(par * taps + tp) * (ctot / 16) + (c >> 4));
     packed[(chunk * 4 + (2 * (k & 1) + (k >> 3))) * ((long)wstride * 4) + (long)co * 4 + ((k >> 1) & 3)] = v;
+}
+
+// bf16x6 image: [par][tap][chunk][3 terms][2 k-halves][wstride][8 bf16]  (conv_halo_emu_kernel)
+__global__ void __launch_bounds__(256)
+pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, unsigned short* __restrict__ packed, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int par, tp, c, co, taps, ctot, wstride;
+    gemm_weight_index(d, i, par, tp, c, co, taps, ctot, wstride);
+    const float v = gemm_weight(d, w, par, tp, c, co);
+    unsigned h, m, l;
+    split_bf16x3(v, 0.0f, h, m, l);
+    const unsigned term[3] = {h & 0xffffu, m & 0xffffu, l & 0xffffu};
+    const int k = c & 15;
+    const long chunk = ((long)(par * taps + tp) * (ctot / 16) + (c >> 4));
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+        packed[(((chunk * 3 + t) * 2 + (k >> 3)) * (long)wstride + co) * 8 + (k & 7)] = (unsigned short)term[t];
 }
 
 // mask[tile] = any(alpha > 0) over the 32 x th output pixels of the tile (tile order = the halo kernels' mt index)
@@ -883,6 +1202,12 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->cfg = 2; p->bm = 128; p->bn = 128;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
         p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+    }
+    // bf16x6 emulation: 256 x 128 tiles (32 x 8 pixels, two waves per SIMD) halve the weight traffic and barriers per MFMA
+    if ((d->flags & RNR_CONV_F32_EMU_BF16X6) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
+        p->Ho % 8 == 0) {
+        p->bm = 256;
+        p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
     const int th = p->bm / 32;
     p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
@@ -933,7 +1258,8 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
                 "%s: c_in1 %d / pad %d", who, d->c_in1, d->c_in1_pad);
     RNR_REQUIRE(d->c_out > 0 && d->c_out_pad >= d->c_out && d->c_out_pad % BK == 0,
                 "%s: c_out %d / pad %d", who, d->c_out, d->c_out_pad);
-    RNR_REQUIRE((d->flags & ~RNR_CONV_STATS_PREZEROED) == 0, "%s: unknown flags 0x%x", who, d->flags);
+    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_BF16X6)) == 0, "%s: unknown flags 0x%x", who,
+                d->flags);
     return 0;
 }
 
@@ -941,19 +1267,31 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
 
 using namespace rnr;
 
+static size_t packed_f32_floats(const rnr_conv_desc* d) {
+    const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : 16;          // 16 = 4x4 taps, or 4 parity classes x 4 taps
+    return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
+}
+
 extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
     if (!d) return 0;
-    const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : (d->kind == RNR_CONV4x4S2_REFLECT ? 16 : 16);
-    return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
+    const size_t f32 = packed_f32_floats(d);
+    // bf16x6 image behind the fp32 image: 3 bf16 terms = 6 bytes per weight
+    return (d->flags & RNR_CONV_F32_EMU_BF16X6) ? f32 + (f32 * 6 + 3) / 4 : f32;
 }
 
 extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream) {
     if (int e = check_desc(d, "rnr_pack_conv_weight")) return e;
     RNR_REQUIRE(weight && packed, "rnr_pack_conv_weight: null pointer argument");
-    const long total = (long)rnr_packed_weight_floats(d);
+    const long total = (long)packed_f32_floats(d);
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        *d, weight, packed, total);
-    return check_launch("pack_weight_kernel");
+    if (int e = check_launch("pack_weight_kernel")) return e;
+    if (d->flags & RNR_CONV_F32_EMU_BF16X6) {
+        hipLaunchKernelGGL(pack_weight_emu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           *d, weight, reinterpret_cast<unsigned short*>(packed + total), total);
+        return check_launch("pack_weight_emu_kernel");
+    }
+    return 0;
 }
 
 extern "C" size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
@@ -1041,7 +1379,24 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.out = out_raw;
         P.slab_stride = 0;
     }
-    if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
+    // bf16x6 emulation: 3x3 and transposed convolutions on the halo plan with 64- or 128-column tiles
+    const bool emu = (d->flags & RNR_CONV_F32_EMU_BF16X6) && pl.halo && d->kind != RNR_CONV4x4S2_REFLECT;
+    if (emu) {
+        P.weight_emu = weight_packed + packed_f32_floats(d);
+        const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
+        if (d->kind == RNR_CONV3x3_REFLECT) {
+            if (pl.cfg == 0) launch_halo_emu_cfg<0, 4, 1, 2, 2>(grid, P, st);
+            else if (pl.cfg == 1) launch_halo_emu_cfg<0, 4, 1, 2, 3>(grid, P, st);      // 256 x 96 (Cout 78)
+            else if (pl.bm == 256) launch_halo_emu_cfg<0, 2, 2, 4, 2>(grid, P, st);
+            else launch_halo_emu_cfg<0, 2, 2, 2, 2>(grid, P, st);
+        } else {
+            if (pl.cfg == 0) launch_halo_emu_cfg<2, 4, 1, 2, 2>(grid, P, st);
+            else if (pl.cfg == 1) launch_halo_emu_cfg<2, 4, 1, 2, 3>(grid, P, st);
+            else if (pl.bm == 256) launch_halo_emu_cfg<2, 2, 2, 4, 2>(grid, P, st);
+            else launch_halo_emu_cfg<2, 2, 2, 2, 2>(grid, P, st);
+        }
+    }
+    else if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
     else if (pl.halo && d->kind == RNR_CONV4x4S2_REFLECT) launch_halo<1>(pl, P, st);
     else if (pl.halo) launch_halo<2>(pl, P, st);
     else if (d->kind == RNR_CONV3x3_REFLECT) launch_kind<0>(pl, P, st);

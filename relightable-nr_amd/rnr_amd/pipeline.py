@@ -18,7 +18,7 @@ from .unet import UNetPlan
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
                  sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10,
-                 skip_background_tiles=True, streams=1):
+                 skip_background_tiles=True, streams=1, precision='f32'):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
@@ -57,9 +57,11 @@ class RNRPipeline:
         self.n_streams = min(self.n_streams, self.max_views)
         lane_views = (self.max_views + self.n_streams - 1) // self.n_streams
         self.unet = UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
-                             (self.S, self.S), lane_views if self.n_streams > 1 else self.max_views, self.dev)
+                             (self.S, self.S), lane_views if self.n_streams > 1 else self.max_views, self.dev,
+                             precision=precision)
         self._lane_unets = [self.unet] + [UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
-                                                   (self.S, self.S), lane_views, self.dev, share_weights_with=self.unet)
+                                                   (self.S, self.S), lane_views, self.dev, share_weights_with=self.unet,
+                                                   precision=precision)
                                           for _ in range(self.n_streams - 1)]
         self._lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)] if self.n_streams > 1 else []
         self.sh_lighting, self.sh_coeff = None, None

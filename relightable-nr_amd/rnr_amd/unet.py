@@ -33,11 +33,17 @@ class _Act:
 
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
-                 prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None):
+                 prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None, precision='f32'):
         """bn_mode 'batch': BatchNorm2d in train mode (per-view batch statistics, what test_rnr.py:229-233 forces);
         'running': eval-mode BatchNorm from the running_mean / running_var buffers of the state-dict.
+        precision 'f32': exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  'bf16x6': fp32 emulated on the bf16 matrix cores —
+        operands split exactly into three bf16 terms, six partial products accumulated in fp32; error of the order of
+        fp32's own rounding, fewer MFMA cycles (include/rnr_hip.h, RNR_CONV_F32_EMU_BF16X6).
         share_weights_with: another UNetPlan of the same network whose packed weights / BN parameters are reused
         (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
+        if precision not in ('f32', 'bf16x6'):
+            raise ValueError("precision must be 'f32' or 'bf16x6'")
+        self.precision = precision
         self.L = _lib.load()
         self.dev = device
         self.N = int(max_views)
@@ -58,6 +64,8 @@ class UNetPlan:
             s0 = srcs[0]
             s1 = srcs[1] if len(srcs) > 1 else None
             desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
+            if precision == 'bf16x6':
+                desc.flags |= _lib.CONV_F32_EMU_BF16X6
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
             else:
@@ -84,7 +92,7 @@ class UNetPlan:
                 out.scale = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
                 out.shift = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
                 # statistics start at zero and every rnr_bn_finalize_reset leaves them at zero: no memset per layer
-                desc.flags = _lib.CONV_STATS_PREZEROED
+                desc.flags |= _lib.CONV_STATS_PREZEROED
                 step['bn'] = {'gamma': gamma, 'beta': beta,
                               'stats': torch.zeros(self.N, desc.c_out_pad, 2, dtype=torch.float64, device=device)}
             elif bias_key is not None and has(bias_key):

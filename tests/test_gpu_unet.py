@@ -20,7 +20,7 @@ def _act(x, a):
     return F.leaky_relu(x, 0.2) if a == 1 else (F.relu(x) if a == 2 else x)
 
 
-def run_conv(kind, srcs, weight, c_out, N, H, W):
+def run_conv(kind, srcs, weight, c_out, N, H, W, flags=0):
     """srcs: list of (raw NCHW cpu tensor, scale [N,C] or None, shift [N,C] or None, act)."""
     from rnr_amd import _lib
     from rnr_amd.ops import _ptr, _stream
@@ -43,7 +43,7 @@ def run_conv(kind, srcs, weight, c_out, N, H, W):
                                     shd.data_ptr() if shd is not None else None, cp, act))
         cs.append((C, cp))
     desc = _lib.RnrConvDesc(kind, cs[0][0], cs[0][1], cs[1][0] if len(cs) > 1 else 0, cs[1][1] if len(cs) > 1 else 0,
-                            c_out, pad16(c_out))
+                            c_out, pad16(c_out), flags)
     packed = torch.empty(L.rnr_packed_weight_floats(ctypes.byref(desc)), device=DEV)
     wd = weight.contiguous().to(DEV)
     _lib.check(L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(wd), _ptr(packed), _stream()))
@@ -126,6 +126,47 @@ def test_conv_vs_torch(kind, N, H, W, cins, c_out):
     s2 = (ref * ref).sum(dim=(1, 2))
     assert torch.allclose(stats[:, :c_out, 0], s1, rtol=1e-4, atol=1e-3 * float(scale) * H * W ** 0.5)
     assert torch.allclose(stats[:, :c_out, 1], s2, rtol=1e-4)
+
+
+EMU_CASES = [
+    (0, 1, 64, 64, [112], 64),         # 256x64 tiles, 7 chunks
+    (0, 2, 32, 64, [64, 64], 128),     # 128x128 tiles, skip concat, two views
+    (0, 1, 64, 64, [256], 256),        # split-K over chunks
+    (2, 1, 32, 32, [64, 64], 64),      # transposed conv, 256x64 tiles
+    (2, 2, 32, 64, [128], 128),        # transposed conv, 128x128 tiles
+    (0, 2, 32, 64, [64], 78),          # 80-column layer: not covered, must fall back to the fp32 kernel from the same buffer
+    (1, 1, 64, 64, [64], 128),         # 4x4 s2: not covered either
+]
+
+
+@pytest.mark.parametrize('kind,N,H,W,cins,c_out', EMU_CASES)
+def test_conv_f32_emulation_bf16x6(kind, N, H, W, cins, c_out):
+    """RNR_CONV_F32_EMU_BF16X6: the bf16x6 split on the bf16 matrix cores must be as close to a float64 convolution as
+    the exact-fp32 MFMA path is (its error is fp32 accumulation rounding, not the split)."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(7 + kind + H + c_out)
+    srcs = []
+    for j, C in enumerate(cins):
+        raw = torch.randn(N, C, H, W, generator=g) * (3.0 if j == 0 else 0.05)       # mixed magnitudes
+        sc = torch.rand(N, C, generator=g) + 0.5 if j == 0 else None
+        sh = torch.randn(N, C, generator=g) * 0.3
+        srcs.append((raw, sc, sh, 1 if j == 0 else 2))
+    cin = sum(cins)
+    k = 4 if kind else 3
+    w = (torch.randn(cin, c_out, 4, 4, generator=g) if kind == 2 else torch.randn(c_out, cin, k, k, generator=g)) / (cin * k * k) ** 0.5
+    ref = ref_conv(kind, srcs, w).permute(0, 2, 3, 1)
+    f32, st32 = run_conv(kind, srcs, w, c_out, N, H, W)
+    emu, stemu = run_conv(kind, srcs, w, c_out, N, H, W, flags=_lib.CONV_F32_EMU_BF16X6)
+    e32 = (f32[..., :c_out].double() - ref).abs()
+    eemu = (emu[..., :c_out].double() - ref).abs()
+    scale = float(ref.abs().max())
+    assert torch.isfinite(emu).all()
+    assert eemu.max() < 1e-4 * scale
+    # same error class as exact fp32: rms within 1.5x, max within 3x (usually it is the smaller of the two)
+    assert eemu.pow(2).mean().sqrt() <= 1.5 * e32.pow(2).mean().sqrt() + 1e-9 * scale, (eemu.pow(2).mean().sqrt(), e32.pow(2).mean().sqrt())
+    assert eemu.max() <= 3.0 * e32.max() + 1e-8 * scale
+    assert torch.allclose(stemu[:, :c_out, 0], st32[:, :c_out, 0], rtol=1e-4, atol=1e-3 * scale * H * W ** 0.5)
+    assert torch.allclose(stemu[:, :c_out, 1], st32[:, :c_out, 1], rtol=1e-4)
 
 
 def _sd(g):
