@@ -744,16 +744,18 @@ __device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned& h, un
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 __global__ void __launch_bounds__(CTHREADS, WM * WN <= 4 ? RNR_HALO_WAVES : 2)
 conv_halo_emu_kernel(const ConvParams P) {
-    static_assert(KIND == 0 || KIND == 2, "3x3 and transposed 4x4-s2 convolutions");
     static_assert(WAVES_M * WAVES_N == 4 && BK == 16, "four waves, 16-channel chunks");
     constexpr int TW = 32, TH = WAVES_M * WM;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int TAPS = KIND == 0 ? 9 : 4;
-    constexpr int HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
+    constexpr int HWD = KIND == 1 ? 2 * TW + 2 : TW + 2;
+    constexpr int HHT = KIND == 1 ? 2 * TH + 2 : TH + 2;
+    constexpr int HP = HWD * HHT;
     constexpr int ASLOTS = HP * 4;
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
     constexpr int APL = 2 * HP * 16, BPL = 2 * BN * 16;       // bytes per term plane (two k-halves)
     constexpr int ACHB = 3 * APL, BCHB = 3 * BPL;             // bytes per chunk image
+    constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;        // halo pixels between consecutive output rows
     constexpr int RUNS = (BN + 63) / 64;
     constexpr int NPB = 6 * RUNS;                             // DMA pieces per weight tile: (term, k-half, 64-column run)
     constexpr int BPT = (NPB + 3) / 4;
@@ -789,15 +791,18 @@ conv_halo_emu_kernel(const ConvParams P) {
         if (s >= ASLOTS) s -= ASLOTS;
         const int hp = s >> 2;
         const int hy = hp / HWD, hx = hp - hy * HWD;
-        int iy, ix;
+        int iy, ix, col = hx;
         if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
-        else {
+        else if (KIND == 1) {
+            iy = reflect1(2 * y0 - 1 + hy, P.H); ix = reflect1(2 * x0 - 1 + hx, P.W);
+            col = (hx & 1) * (HWD / 2) + (hx >> 1);                 // de-interleave even | odd columns
+        } else {
             iy = y0 - 1 + hy; ix = x0 - 1 + hx;
             const bool inside = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
             smask[j] = inside ? 1.f : 0.f;
             iy = min(max(iy, 0), P.H - 1); ix = min(max(ix, 0), P.W - 1);
         }
-        sdst[j] = ((q >> 1) * HP + hp) * 16 + (q & 1) * 8;      // k-half = channels 8*(q>>1) .., 4 bf16 at (q&1)*4
+        sdst[j] = ((q >> 1) * HP + hy * HWD + col) * 16 + (q & 1) * 8;      // k-half = channels 8*(q>>1) .., 4 bf16 at (q&1)*4
         spix[j] = (unsigned)(iy * P.W + ix);
     }
 
@@ -872,7 +877,7 @@ conv_halo_emu_kernel(const ConvParams P) {
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
-    const int wrow = wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
     const char* a_lane = As + (h * HP + wrow + l31) * 16;
     const char* b_lane = Bs + (h * BN + wn0 + l31) * 16;
 
@@ -902,6 +907,7 @@ conv_halo_emu_kernel(const ConvParams P) {
             }
             int aoff;
             if (KIND == 0) { const int ky = (t * 11) >> 5; aoff = ky * HWD + (t - 3 * ky); }      // t / 3 for t < 9
+            else if (KIND == 1) aoff = (t >> 2) * HWD + (t & 1) * (HWD / 2) + ((t & 3) >> 1);
             else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
             const char* a_s = a_lane + aoff * 16;
             const char* b_s = b_lane + (step & 1) * BCHB;
@@ -916,7 +922,7 @@ conv_halo_emu_kernel(const ConvParams P) {
             for (int ta = 2; ta >= 0; ta--) {
                 bf16x8 a[WM];
 #pragma unroll
-                for (int i = 0; i < WM; i++) a[i] = *reinterpret_cast<const bf16x8*>(a_s + ta * APL + i * HWD * 16);
+                for (int i = 0; i < WM; i++) a[i] = *reinterpret_cast<const bf16x8*>(a_s + ta * APL + i * ROWSTEP * 16);
                 // a_l pairs with b_h; a_m with b_m, b_h; a_h with b_l, b_m, b_h
 #pragma unroll
                 for (int tb = 2 - ta; tb >= 0; tb--)
@@ -994,7 +1000,8 @@ conv_halo_emu_kernel(const ConvParams P) {
 
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
-    constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32, HP = 34 * (TH + 2);
+    constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32;
+    constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
     constexpr size_t lds = (size_t)(96 * HP + 2 * 96 * BN);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1209,6 +1216,12 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->bm = 256;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
+    // ... and 64 x 128 tiles (32 x 2 pixels) for the 4x4-s2 convolution, whose halo is 5x the tile
+    if ((d->flags & RNR_CONV_F32_EMU_BF16X6) && d->kind == RNR_CONV4x4S2_REFLECT && p->cfg == 2 && p->Wo % 32 == 0 &&
+        p->Ho % 2 == 0) {
+        p->bm = 64;
+        p->mtiles = (p->M + p->bm - 1) / p->bm;
+    }
     const int th = p->bm / 32;
     p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
     // the halo kernels address a view with 32-bit element offsets
@@ -1380,11 +1393,13 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.slab_stride = 0;
     }
     // bf16x6 emulation: 3x3 and transposed convolutions on the halo plan with 64- or 128-column tiles
-    const bool emu = (d->flags & RNR_CONV_F32_EMU_BF16X6) && pl.halo && d->kind != RNR_CONV4x4S2_REFLECT;
+    const bool emu = (d->flags & RNR_CONV_F32_EMU_BF16X6) && pl.halo && (d->kind != RNR_CONV4x4S2_REFLECT || pl.bm == 64);
     if (emu) {
         P.weight_emu = weight_packed + packed_f32_floats(d);
         const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
-        if (d->kind == RNR_CONV3x3_REFLECT) {
+        if (d->kind == RNR_CONV4x4S2_REFLECT) {
+            launch_halo_emu_cfg<1, 2, 2, 1, 2>(grid, P, st);        // 64 x 128 (make_plan forces the 128-column config)
+        } else if (d->kind == RNR_CONV3x3_REFLECT) {
             if (pl.cfg == 0) launch_halo_emu_cfg<0, 4, 1, 2, 2>(grid, P, st);
             else if (pl.cfg == 1) launch_halo_emu_cfg<0, 4, 1, 2, 3>(grid, P, st);      // 256 x 96 (Cout 78)
             else if (pl.bm == 256) launch_halo_emu_cfg<0, 2, 2, 4, 2>(grid, P, st);

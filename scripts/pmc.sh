@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/bench.py --views-per-step ${VIEWS:-4} --steps 2 --warmup 1 --no-cpu-baseline --no-parity --main-loop-only > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/bench.py --views-per-step ${VIEWS:-4} --steps 2 --warmup 1 --no-cpu-baseline --no-parity --main-loop-only --precision ${PRECISION:-f32} > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python $GRAFT_REPO_ROOT/scripts/pmc_merge.py $OUT

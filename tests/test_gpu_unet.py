@@ -134,8 +134,11 @@ EMU_CASES = [
     (0, 1, 64, 64, [256], 256),        # split-K over chunks
     (2, 1, 32, 32, [64, 64], 64),      # transposed conv, 256x64 tiles
     (2, 2, 32, 64, [128], 128),        # transposed conv, 128x128 tiles
-    (0, 2, 32, 64, [64], 78),          # 80-column layer: not covered, must fall back to the fp32 kernel from the same buffer
-    (1, 1, 64, 64, [64], 128),         # 4x4 s2: not covered either
+    (0, 2, 32, 64, [64], 78),          # 80-column layer on 256 x 96 tiles
+    (1, 1, 64, 64, [64], 128),         # 4x4 s2, 32x2 tiles
+    (1, 2, 64, 128, [32], 16),         # 4x4 s2, narrow output on the 128-column config, two views
+    (1, 1, 128, 64, [128], 256),       # 4x4 s2, two column tiles
+    (0, 1, 16, 16, [64, 64], 128),     # map narrower than 32 px: not covered, falls back to the fp32 kernel from the same buffer
 ]
 
 
