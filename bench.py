@@ -67,7 +67,7 @@ def build_scene(args):
     }
 
 
-def cpu_baseline(sc, args, view_id, hip_image):
+def cpu_baseline(sc, args, view_id, hip_image, emu_image=None):
     """The oracle (a port of the reference's algorithm) timed on this box's host cores on ONE frame of the same
     workload; also yields the parity figure (PSNR of the HIP frame vs the oracle frame)."""
     from oracle import rnr_oracle as orc
@@ -98,6 +98,9 @@ def cpu_baseline(sc, args, view_id, hip_image):
     if hip_image is not None:
         parity = {'psnr_db_vs_oracle': orc.psnr(hip_image.cpu(), ref['image']),
                   'max_abs_err': float((hip_image.cpu() - ref['image']).abs().max())}
+        if emu_image is not None:
+            parity['bf16x6_psnr_db_vs_oracle'] = orc.psnr(emu_image.cpu(), ref['image'])
+            parity['bf16x6_max_abs_err'] = float((emu_image.cpu() - ref['image']).abs().max())
     return out, parity
 
 
@@ -197,6 +200,7 @@ def main():
     dt = time.perf_counter() - t0
     pipe.unet.forward = orig_forward
     last_frame = img[V - 1:V].clone()       # the frame buffers are reused by the extra renders below
+    emu_last = None
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,23 +265,24 @@ def main():
                              **({'alg_bytes_per_step': alg[k] * V, 'GB/s': alg[k] * V / (acc[k] * 1e-3) / 1e9,
                                  'frac_of_hbm_peak': alg[k] * V / (acc[k] * 1e-3) / 1e9 / PEAK_HBM_GBS} if k in alg else {})}
                          for k in acc}
+        def timed(p):
+            def st(s):
+                lo = s * V
+                sl = slice(lo, lo + V)
+                return p.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+            for s in range(2):
+                st(s)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(args.warmup, args.warmup + args.steps):
+                st(s)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
         if extras and world == 1 and not args.tile_skip and out_tiles_per_step:
             # product-tuned configuration of RNRPipeline, reported beside the headline (frames are bit-identical /
             # equal to 1e-6): out-layer pixel tiles without a foreground pixel are not computed, and the batch is split
             # over two HIP streams so that kernel tails overlap
-            def timed(p):
-                def st(s):
-                    lo = s * V
-                    sl = slice(lo, lo + V)
-                    return p.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
-                for s in range(2):
-                    st(s)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for s in range(args.warmup, args.warmup + args.steps):
-                    st(s)
-                torch.cuda.synchronize()
-                return time.perf_counter() - t1
             pipe.skip_background_tiles = True
             dts = timed(pipe)
             frac = float(pipe.unet._tile_mask[:out_tiles_per_step].float().mean().item())
@@ -294,6 +299,25 @@ def main():
                                                        'ms_per_step': dt2 / args.steps * 1e3,
                                                        'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
                 del pipe2
+        if extras and world == 1 and args.precision == 'f32':
+            # fp32 emulated on the bf16 matrix cores (RNR_CONV_F32_EMU_BF16X6), same tuned configuration
+            pipe3 = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
+                                sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
+                                sh_lmax=10, skip_background_tiles=False, precision='bf16x6')
+            lo = (args.warmup + args.steps - 1) * V
+            sl = slice(lo, lo + V)
+            emu_img = pipe3.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+            native = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+            diff = float((emu_img - native).abs().max())
+            emu_last = emu_img[V - 1:V].clone()
+            dt3 = timed(pipe3)
+            res['with_f32_emulation_bf16x6'] = {
+                'frames_per_s': args.steps * V / dt3, 'ms_per_step': dt3 / args.steps * 1e3,
+                'max_abs_diff_vs_f32_mfma_frames': diff,
+                'note': 'RNRPipeline(precision="bf16x6"): every conv operand split exactly into 3 bf16 terms, 6 partial '
+                        'products accumulated in fp32 on v_mfma_f32_32x32x16_bf16; full compute on every pixel, one stream; '
+                        'not the headline value'}
+            del pipe3
         if world == 1 and V > 1 and extras:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
@@ -314,7 +338,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             last_id = int(ids[(args.warmup + args.steps - 1) * V + V - 1])
             hip_last = None if args.no_parity else last_frame
-            cb, parity = cpu_baseline(sc, args, last_id, hip_last)
+            cb, parity = cpu_baseline(sc, args, last_id, hip_last, emu_last)
             res['cpu_baseline'] = cb
             if parity:
                 res['parity'] = parity

@@ -753,7 +753,8 @@ conv_halo_emu_kernel(const ConvParams P) {
     constexpr int HP = HWD * HHT;
     constexpr int ASLOTS = HP * 4;
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
-    constexpr int APL = 2 * HP * 16, BPL = 2 * BN * 16;       // bytes per term plane (two k-halves)
+    constexpr int BNL = (BN + 63) / 64 * 64;                  // columns of the LDS weight image: whole 64-lane DMA pieces
+    constexpr int APL = 2 * HP * 16, BPL = 2 * BNL * 16;      // bytes per term plane (two k-halves)
     constexpr int ACHB = 3 * APL, BCHB = 3 * BPL;             // bytes per chunk image
     constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;        // halo pixels between consecutive output rows
     constexpr int RUNS = (BN + 63) / 64;
@@ -787,6 +788,9 @@ conv_halo_emu_kernel(const ConvParams P) {
     float smask[KIND == 2 ? APT : 1];
 #pragma unroll
     for (int j = 0; j < APT; j++) {
+        // slots past the halo only fetch (a valid address, the value is never stored): storing them as duplicates of an
+        // earlier slot, as conv_halo_kernel does, produced sporadically corrupted 16-lane groups in this kernel's
+        // three-plane ds_write_b64 pattern on gfx950 (tests/test_gpu_unet.py::test_emulation_halo_swap_stress)
         int s = tid + CTHREADS * j;
         if (s >= ASLOTS) s -= ASLOTS;
         const int hp = s >> 2;
@@ -853,15 +857,15 @@ conv_halo_emu_kernel(const ConvParams P) {
         const int pc = wave_u + 4 * b;
         const int g = pc / RUNS, run = pc - g * RUNS;           // g = term * 2 + k-half
         bvoff[b] = ((unsigned)g * (unsigned)P.wstride + (unsigned)(n0 + 64 * run + lane)) * 16u;
-        blds[b] = (g * BN + 64 * run) * 16;
-        blive[b] = pc < NPB && (BN % 64 == 0 || lane < BN - 64 * run);     // 96-column tiles: 64 + 32 columns
+        blds[b] = (g * BNL + 64 * run) * 16;
+        blive[b] = pc < NPB;
     }
     const char* wemu = reinterpret_cast<const char*>(P.weight_emu);
     auto dma_b = [&](int c, int t, int buf) {
         const char* wt = wemu + ((size_t)(par * TAPS + t) * nchunks + c) * (96 * (size_t)P.wstride);
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
-            if ((NPB % 4 == 0 && BN % 64 == 0) || blive[b]) {
+            if (NPB % 4 == 0 || blive[b]) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + bvoff[b]),
                                                  (__attribute__((address_space(3))) void*)(Bs + buf * BCHB + blds[b]),
                                                  16, 0, 0);
@@ -879,12 +883,13 @@ conv_halo_emu_kernel(const ConvParams P) {
 
     const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
     const char* a_lane = As + (h * HP + wrow + l31) * 16;
-    const char* b_lane = Bs + (h * BN + wn0 + l31) * 16;
+    const char* b_lane = Bs + (h * BNL + wn0 + l31) * 16;
 
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
 #pragma unroll
-        for (int j = 0; j < APT; j++) store_a(cs, load_a(cs, j), j);
+        for (int j = 0; j < APT; j++)
+            if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j);
         dma_b(c_begin, 0, 0);
     }
     __syncthreads();
@@ -895,16 +900,20 @@ conv_halo_emu_kernel(const ConvParams P) {
         // the whole next halo is requested up front and parked in registers; the tap loop is NOT unrolled: unrolled, the
         // scheduler hoists the LDS reads of later taps until the register file spills
         float4 av_all[APT];
+#ifndef RNR_ABLATE_EMU_NOHALO
         if (next_chunk) {
 #pragma unroll
             for (int j = 0; j < APT; j++) av_all[j] = load_a(csn, j);
         }
+#endif
 #pragma unroll 1
         for (int t = 0; t < TAPS; t++, step++) {
             const bool more = next_chunk || t < TAPS - 1;
+#ifndef RNR_ABLATE_EMU_NODMA
             if (more) {
                 if (t < TAPS - 1) dma_b(c, t + 1, (step + 1) & 1); else dma_b(c + 1, 0, (step + 1) & 1);
             }
+#endif
             int aoff;
             if (KIND == 0) { const int ky = (t * 11) >> 5; aoff = ky * HWD + (t - 3 * ky); }      // t / 3 for t < 9
             else if (KIND == 1) aoff = (t >> 2) * HWD + (t & 1) * (HWD / 2) + ((t & 3) >> 1);
@@ -932,13 +941,18 @@ conv_halo_emu_kernel(const ConvParams P) {
                         for (int j = 0; j < WN; j++)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[tb][j], acc[i][j], 0, 0, 0);
             }
+#ifndef RNR_ABLATE_EMU_NOBARRIER
             __syncthreads();
+#endif
         }
+#ifndef RNR_ABLATE_EMU_NOHALO
         if (next_chunk) {       // every wave is past the last tap's reads: swap the next halo in
 #pragma unroll
-            for (int j = 0; j < APT; j++) store_a(csn, av_all[j], j);
+            for (int j = 0; j < APT; j++)
+                if (tid + CTHREADS * j < ASLOTS) store_a(csn, av_all[j], j);
             __syncthreads();
         }
+#endif
     }
 
     // ---- epilogue (identical to conv_halo_kernel: same accumulator layout) ----
@@ -1002,7 +1016,7 @@ template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32;
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds = (size_t)(96 * HP + 2 * 96 * BN);
+    constexpr size_t lds = (size_t)(96 * HP + 2 * 96 * ((BN + 63) / 64 * 64));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<KIND, WAVES_M, WAVES_N, WM, WN>),

@@ -126,6 +126,26 @@ def test_stream_lanes_match_single_stream():
     assert (call(lanes, 5) - first).abs().max() < 2e-5
 
 
+def test_bf16x6_emulation_frame():
+    """precision='bf16x6' (fp32 emulated on the bf16 matrix cores): the frame is as close to the oracle as the exact-fp32
+    frame is, and the two differ by float-rounding noise only."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    sc = testing.tiny_scene(img_size=256, nf0=16, tex_size=128, tex_ch=24, nlat=61, nlon=122, seed=1)
+    mk = lambda prec: RNRPipeline(sc['mesh'], 256, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'],
+                                  sc['lp'], nf0=16, max_views=2, device=DEV, precision=prec)
+    views = {k: T(v) for k, v in scene.spiral_views(256, [40, 400]).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    f32 = mk('f32').render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv']).cpu()
+    emu = mk('bf16x6').render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv']).cpu()
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    ref = orc.render_frame(mesh_t, views, 256, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'], sc['pivots_diff'])
+    p32, pemu = orc.psnr(f32, ref['image']), orc.psnr(emu, ref['image'])
+    assert pemu > 55.0 and pemu > p32 - 3.0, (pemu, p32)
+    assert (emu - f32).abs().max() < 2e-4, (emu - f32).abs().max()
+
+
 def test_all_background_view():
     """Camera looking away from the mesh: every pixel is background (face index -1 wraps to the last face with zero
     weights, uv = (0,0), rays_uv = -1, network.py:176-190, 469-470).  The frame must still match the oracle."""

@@ -172,6 +172,20 @@ def test_conv_f32_emulation_bf16x6(kind, N, H, W, cins, c_out):
     assert torch.allclose(stemu[:, :c_out, 1], st32[:, :c_out, 1], rtol=1e-4)
 
 
+def test_emulation_halo_swap_stress():
+    """Regression: at 512^2 the 256x96 bf16x6 kernel once produced sporadically corrupted 16-lane groups of its halo
+    (duplicate stores of the slots past the halo).  Ten launches of the out-layer shape must all agree with fp32."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    N, H, W, cins, c_out = 1, 512, 512, [64, 64], 78
+    srcs = [(torch.randn(N, C, H, W, generator=g), None, torch.randn(N, C, generator=g) * 0.3, 1) for C in cins]
+    w = torch.randn(c_out, sum(cins), 3, 3, generator=g) / (sum(cins) * 9) ** 0.5
+    nat, _ = run_conv(0, srcs, w, c_out, N, H, W)
+    for rep in range(10):
+        emu, _ = run_conv(0, srcs, w, c_out, N, H, W, flags=_lib.CONV_F32_EMU_BF16X6)
+        assert (emu - nat).abs().max() < 1e-4, rep
+
+
 def _sd(g):
     return {k[3:]: T(g[k]) for k in g.files if k.startswith('sd:')}
 
