@@ -318,6 +318,16 @@ def main():
                         'products accumulated in fp32 on v_mfma_f32_32x32x16_bf16; full compute on every pixel, one stream; '
                         'not the headline value'}
             del pipe3
+            if True:
+                pipe4 = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
+                                    sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
+                                    sh_lmax=10, skip_background_tiles=True, streams=1, precision='bf16x6')
+                dt4 = timed(pipe4)
+                res['with_all_opt_in_fast_paths'] = {
+                    'frames_per_s': args.steps * V / dt4, 'ms_per_step': dt4 / args.steps * 1e3,
+                    'note': 'RNRPipeline(precision="bf16x6", skip_background_tiles=True), one stream (two streams do not help the '
+                            'emulation kernels); not the headline value'}
+                del pipe4
         if world == 1 and V > 1 and extras:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
