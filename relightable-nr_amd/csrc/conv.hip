@@ -28,6 +28,9 @@ constexpr int CTHREADS = 256;
 #define RNR_SPLITK_BELOW 256
 #define RNR_SPLITK_TARGET 512
 #endif
+#ifndef RNR_NATIVE_BIG_MIN
+#define RNR_NATIVE_BIG_MIN 512     // measured: 512 >= 1024, 2048 at 8, 4, 2 views per launch, all equal at 1
+#endif
 #ifndef RNR_HALO_WAVES
 #define RNR_HALO_WAVES 3    // waves per SIMD the halo kernels are register-bounded for (4 would spill and exceed LDS anyway)
 #endif
@@ -366,7 +369,7 @@ conv_mfma_kernel(const ConvParams P) {
 // registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
-__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 4 ? 2 : 1))
+__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
     constexpr int TW = 32, TH = WAVES_M * WM;
     // R16 = 1 adds a 16-column remainder tile per wave on v_mfma_f32_16x16x4_f32 (same FLOP rate): Cout = 78 runs as
@@ -1230,6 +1233,13 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->bm = 256;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
+    // exact-fp32 kernels: 256 x 128 tiles (two waves per SIMD, half the weight traffic and barriers per MFMA) once there
+    // are enough of them to fill the 256 CUs twice over; below that the 128 x 128 tiles keep more CUs busy
+    if (!(d->flags & RNR_CONV_F32_EMU_BF16X6) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
+        p->Ho % 8 == 0 && (long)(p->M / 256) * p->ntiles * p->par >= RNR_NATIVE_BIG_MIN) {
+        p->bm = 256;
+        p->mtiles = (p->M + p->bm - 1) / p->bm;
+    }
     // ... and 64 x 128 tiles (32 x 2 pixels) for the 4x4-s2 convolution, whose halo is 5x the tile
     if ((d->flags & RNR_CONV_F32_EMU_BF16X6) && d->kind == RNR_CONV4x4S2_REFLECT && p->cfg == 2 && p->Wo % 32 == 0 &&
         p->Ho % 2 == 0) {
@@ -1265,6 +1275,7 @@ static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st)
     const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
     if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
     else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 2, 1>(grid, P, st);      // 256 x 80
+    else if (pl.bm == 256 && KIND != 1) launch_halo_cfg<KIND == 1 ? 0 : KIND, 2, 2, 4, 2, 0>(grid, P, st);
     else launch_halo_cfg<KIND, 2, 2, 2, 2, 0>(grid, P, st);
 }
 

@@ -97,6 +97,8 @@ CASES = [
     (2, 1, 32, 32, [64, 64], 64),      # transposed conv halo kernel, 32x8 tiles, concat
     (2, 2, 32, 64, [128], 128),        # transposed conv halo kernel, 32x4 tiles
     (2, 1, 8, 32, [256], 78),          # transposed conv halo, 256x96 config, split-K
+    (0, 1, 512, 512, [16], 128),       # enough tiles for the 256x128 fp32 config (two waves per SIMD)
+    (2, 1, 256, 256, [16, 16], 128),   # the same for the transposed conv, concat input
 ]
 
 
