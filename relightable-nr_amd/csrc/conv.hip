@@ -15,6 +15,10 @@
 //                 concat are pure index arithmetic on the gather;
 //   * epilogue  : per-view per-channel sum / sum-of-squares of the raw output (wave shuffles -> LDS ->
 //                 one fp64 atomic per channel per workgroup) for the next BatchNorm's batch statistics.
+//
+// Kernels: conv_halo_kernel (LDS-halo tiles, exact fp32: every map >= 32 px wide), conv_mfma_kernel (tap-by-tap gather:
+// the small maps), conv_halo_emu_kernel (opt-in: fp32 emulated on the bf16 matrix cores, RNR_CONV_F32_EMU_BF16X6).
+// make_plan() picks the kernel, the tile shape (256x64, 256x80, 128x128 or 256x128 rows x columns) and the split-K depth.
 #include "rnr_internal.h"
 
 namespace rnr {
@@ -1199,7 +1203,7 @@ __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restric
 
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
-    int cfg;        // 0: 256x64, 1: 256x96, 2: 128x128
+    int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
     int Ho, Wo, OH, OW, M;
     int taps, chunks_per_tap, kt_total;
