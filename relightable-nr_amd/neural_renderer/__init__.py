@@ -5,8 +5,7 @@
 
 The rasterizer is differentiable (RasterizeFunction: HIP backward kernels for the rgb/alpha/depth maps and textures).
 Textured OBJ loading / saving (load_obj(load_texture=True), save_obj) run the load_textures / create_texture_image
-HIP kernels.  Out of scope: look / look_at / perspective camera modes and the Mesh helper; those names
-raise NotImplementedError instead of silently misbehaving.
+HIP kernels; look / look_at / perspective / get_points_from_angles / Mesh are plain tensor utilities.
 """
 from .lighting import lighting
 from .load_obj import load_obj
@@ -18,18 +17,8 @@ from .vertices_to_faces import vertices_to_faces
 from .vertices_to_faces import vertex_attrs_to_faces
 
 
-def _unsupported(name):
-    def f(*a, **k):
-        raise NotImplementedError('neural_renderer.%s is outside the MI355X hot-path build (SURVEY.md §2.1)' % name)
-    f.__name__ = name
-    return f
-
-
-get_points_from_angles = _unsupported('get_points_from_angles')
-look = _unsupported('look')
-look_at = _unsupported('look_at')
-perspective = _unsupported('perspective')
-Mesh = _unsupported('Mesh')
+from .camera_modes import look_at, look, perspective, get_points_from_angles
+from .mesh import Mesh
 
 __version__ = '1.1.3+rnr_hip'
 name = 'neural_renderer'

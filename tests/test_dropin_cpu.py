@@ -50,8 +50,6 @@ def test_neural_renderer_api_names():
     for name in ['forward_face_index_map', 'forward_texture_sampling', 'backward_pixel_map', 'backward_textures',
                  'backward_depth_map']:
         assert hasattr(ext, name)
-    with pytest.raises(NotImplementedError):
-        nr.look_at(None, None)
     with pytest.raises(RuntimeError):          # real HIP kernels now: CPU tensors are rejected like CHECK_INPUT does
         ext.backward_textures(torch.zeros(1, 4, 4, dtype=torch.int32), torch.zeros(1, 4, 4, 8),
                               torch.zeros(1, 4, 4, 8, dtype=torch.int32), torch.zeros(1, 4, 4, 3),
@@ -133,3 +131,26 @@ def test_view_dataset_matches_reference(golden, tmp_path):
                 assert torch.equal(v[key], again[key])
     with pytest.raises(NotImplementedError):
         dataio.ViewDataset(str(tmp_path), fp, 'convert', [64, 64], 'all', load_img=True)
+
+
+def test_camera_modes_match_reference(golden):
+    """nr.look_at / look / perspective / get_points_from_angles vs the reference package's outputs."""
+    import numpy as np
+    import neural_renderer as nr
+    g = golden('camera_modes')
+    v, eye3 = torch.from_numpy(g['vertices']), torch.from_numpy(g['eye3'])
+    close = lambda a, k: np.allclose(a.numpy(), g[k], rtol=1e-6, atol=1e-6)
+    assert close(nr.look_at(v, [0.3, -0.2, -2.7]), 'look_at_list')
+    assert close(nr.look_at(v, eye3, at=[0.1, 0.0, 0.2], up=[0.0, 1.0, 0.1]), 'look_at_batch')
+    assert close(nr.look(v, [0.3, -0.2, -2.7], direction=[0.1, -0.1, 1.0], up=torch.tensor([0.0, 1.0, 0.0])), 'look')
+    assert close(nr.look(v, [0.3, -0.2, -2.7], direction=[0.1, -0.1, 1.0]), 'look')          # default up = +y
+    assert close(nr.perspective(v + torch.tensor([0.0, 0.0, 4.0]), angle=25.0), 'perspective')
+    assert np.allclose(np.array(nr.get_points_from_angles(2.7, 30.0, -40.0)), g['points_scalar'])
+    pts = nr.get_points_from_angles(torch.tensor([2.0, 2.5, 3.0]), torch.tensor([10.0, -20.0, 45.0]), torch.tensor([0.0, 90.0, 200.0]))
+    assert close(pts, 'points_tensor')
+    with pytest.raises(ValueError):
+        nr.look_at(torch.zeros(4, 3), [0, 0, -1])
+    with pytest.raises(ValueError):
+        nr.Renderer(camera_mode='orbit')
+    r = nr.Renderer(camera_mode='look_at', viewing_angle=30)
+    assert abs(r.eye[2] + (1.0 / np.tan(np.radians(30)) + 1)) < 1e-12

@@ -289,3 +289,38 @@ def test_textured_obj_round_trip(tmp_path):
     # interior texels of each cube sample inside the face's atlas triangle: the flat colour comes back to 8-bit accuracy
     centre = tex2[:, 1, 1, 1, :].cpu()
     assert (centre - colour[:, 0, 0, 0, :]).abs().max() < 2.5 / 255
+
+
+def test_renderer_look_at_modes():
+    """nr.Renderer(camera_mode='look_at'): silhouettes / depth / rgb modes and the 8-tuple, vs the C oracle rasterizer
+    fed with the same look_at + perspective vertices (SSAA off and on)."""
+    import neural_renderer as nr
+    from oracle import raster as oras
+    from rnr_amd import scene
+    mesh = scene.uv_sphere(12, 24)
+    v = torch.from_numpy(mesh['v'] * 0.6)[None].cuda()
+    f = torch.from_numpy(mesh['f_v_idx'])[None].cuda()
+    nf = f.shape[1]
+    tex = torch.rand(1, nf, 2, 2, 2, 3, device='cuda:0')
+    for aa in (False, True):
+        r = nr.Renderer(image_size=64, anti_aliasing=aa, camera_mode='look_at', fill_back=False, viewing_angle=30,
+                        light_intensity_ambient=1.0, light_intensity_directional=0.0)
+        r.eye = nr.get_points_from_angles(2.732, 20.0, 35.0)
+        sil = r(v, f, mode='silhouettes')
+        dep = r(v, f, mode='depth')
+        rgb = r(v, f, tex, mode='rgb')
+        S = 128 if aa else 64
+        vv = nr.perspective(nr.look_at(v, r.eye), angle=30)
+        faces = vv[0][f[0].long()][None].cpu().numpy()
+        o = oras.face_index_map(faces, S, 0.1, 100.0)
+        alpha = torch.from_numpy((o['face_index_map'] >= 0).astype(np.float32)).flip(1)
+        depth = torch.from_numpy(o['depth_map']).flip(1)
+        if aa:
+            pool = lambda x: torch.nn.functional.avg_pool2d(x[:, None], 2)[:, 0]
+            alpha, depth = pool(alpha), pool(depth)
+        assert sil.shape == (1, 64, 64) and 0.05 < float(sil.mean()) < 0.8
+        assert torch.allclose(sil.cpu(), alpha, atol=1e-6)
+        assert torch.allclose(dep.cpu(), depth, rtol=1e-5, atol=1e-4)
+        assert rgb.shape == (1, 3, 64, 64) and float((rgb.cpu().sum(1) > 0).float().mean()) > 0.05
+        out = r(v, f, tex)
+        assert len(out) == 8 and torch.allclose(out[0], rgb) and torch.allclose(out[2], sil)
