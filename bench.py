@@ -265,6 +265,8 @@ def main():
                              **({'alg_bytes_per_step': alg[k] * V, 'GB/s': alg[k] * V / (acc[k] * 1e-3) / 1e9,
                                  'frac_of_hbm_peak': alg[k] * V / (acc[k] * 1e-3) / 1e9 / PEAK_HBM_GBS} if k in alg else {})}
                          for k in acc}
+            res['stages']['raster']['note'] = ('not an HBM-bound stage: 65 k faces are binned and edge-tested per view '
+                                               '(VALU / latency bound); the HBM figure is given for completeness')
         def timed(p):
             def st(s):
                 lo = s * V
