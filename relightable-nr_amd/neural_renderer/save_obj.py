@@ -1,66 +1,71 @@
-"""nr.save_obj / create_texture_image (reference: neural_renderer/save_obj.py:1-82) on the HIP kernels behind
-neural_renderer.cuda.create_texture_image.  The atlas PNG is written with PIL (the reference uses skimage.io.imsave)."""
+"""nr.save_obj / create_texture_image on the HIP atlas kernels (neural_renderer.cuda.create_texture_image).
+
+Same outputs as the reference module (neural_renderer/save_obj.py:10-82): `name.obj` with per-corner `vt` indices,
+`name.mtl` pointing at `name.png`, the atlas holding one right-triangle tile per face.  Written from scratch: the tile
+corners come from one numpy expression, the files are assembled as text blocks; PNG output uses PIL."""
 import os
 
 import numpy as np
 import torch
 
+_MATERIAL = 'material_1'
+
+
+def _tile_grid(num_faces):
+    """Tiles per row / per column of the atlas (save_obj.py:12-13)."""
+    per_row = int((num_faces - 1.) ** 0.5) + 1
+    return per_row, int((num_faces - 1.) / per_row) + 1
+
+
+def _tile_corners(num_faces, per_row, size):
+    """[nf, 3, 2] pixel coordinates of each face's tile triangle: top-left, bottom-left, bottom-right of the tile
+    (save_obj.py:16-24)."""
+    k = np.arange(num_faces)
+    left, top = (k % per_row) * size, (k // per_row) * size
+    right, bottom = left + size - 1, top + size - 1
+    return np.stack([np.stack([left, top], -1), np.stack([left, bottom], -1), np.stack([right, bottom], -1)],
+                    1).astype(np.float32)
+
 
 def create_texture_image(textures, texture_size_out=16):
-    """textures [nf, ts, ts, ts, 3] -> (atlas image [H, W, 3] float numpy, flipped like the reference; vt [nf, 3, 2])."""
-    import neural_renderer.cuda.create_texture_image as create_texture_image_cuda
-    num_faces = textures.shape[0]
-    tile_width = int((num_faces - 1.) ** 0.5) + 1
-    tile_height = int((num_faces - 1.) / tile_width) + 1
-    image = torch.zeros(tile_height * texture_size_out, tile_width * texture_size_out, 3, dtype=torch.float32,
-                        device='cuda')
-    vertices = torch.zeros((num_faces, 3, 2), dtype=torch.float32)
-    face_nums = torch.arange(num_faces)
-    column = (face_nums % tile_width).float()
-    row = (face_nums // tile_width).float()
-    vertices[:, 0, 0] = column * texture_size_out
-    vertices[:, 0, 1] = row * texture_size_out
-    vertices[:, 1, 0] = column * texture_size_out
-    vertices[:, 1, 1] = (row + 1) * texture_size_out - 1
-    vertices[:, 2, 0] = (column + 1) * texture_size_out - 1
-    vertices[:, 2, 1] = (row + 1) * texture_size_out - 1
-    vertices = vertices.cuda()
-    image = create_texture_image_cuda.create_texture_image(vertices, textures.detach().float().contiguous().cuda(),
-                                                           image, 1e-5)
-    vertices[:, :, 0] /= (image.shape[1] - 1)
-    vertices[:, :, 1] /= (image.shape[0] - 1)
-    return image.cpu().numpy()[::-1, ::1], vertices.cpu().numpy()
+    """textures [nf, ts, ts, ts, 3] -> (atlas [H, W, 3] float numpy with row 0 at the bottom like an image file,
+    vt [nf, 3, 2] in [0, 1])."""
+    import neural_renderer.cuda.create_texture_image as ext
+    nf = textures.shape[0]
+    per_row, rows = _tile_grid(nf)
+    corners = torch.from_numpy(_tile_corners(nf, per_row, texture_size_out)).cuda()
+    atlas = torch.zeros(rows * texture_size_out, per_row * texture_size_out, 3, device='cuda')
+    ext.create_texture_image(corners, textures.detach().float().contiguous().cuda(), atlas, 1e-5)
+    vt = corners.cpu().numpy() / np.array([atlas.shape[1] - 1, atlas.shape[0] - 1], np.float32)
+    return atlas.cpu().numpy()[::-1], vt
+
+
+def _obj_text(name, vertices, faces, vt, mtl_name):
+    blocks = ['# %s\n#\n' % name]
+    if vt is not None:
+        blocks.append('mtllib %s\n' % mtl_name)
+    blocks.append(''.join('v %.8f %.8f %.8f\n' % tuple(p) for p in vertices))
+    if vt is None:
+        blocks.append(''.join('f %d %d %d\n' % tuple(f + 1) for f in faces))
+    else:
+        blocks.append(''.join('vt %.8f %.8f\n' % tuple(p) for p in vt.reshape(-1, 2)))
+        corner = 3 * np.arange(len(faces))[:, None] + np.arange(1, 4)[None, :]          # one vt per face corner
+        rows = np.stack([faces + 1, corner], -1).reshape(len(faces), 6)
+        blocks.append('usemtl %s\n' % _MATERIAL + ''.join('f %d/%d %d/%d %d/%d\n' % tuple(r) for r in rows))
+    return '\n'.join(blocks) + '\n'
 
 
 def save_obj(filename, vertices, faces, textures=None):
-    assert vertices.ndimension() == 2
-    assert faces.ndimension() == 2
+    """vertices [nv, 3], faces [nf, 3] (0-based), optional textures [nf, ts, ts, ts, 3]."""
+    assert vertices.ndimension() == 2 and faces.ndimension() == 2
+    stem = filename[:-4]
+    vt = None
     if textures is not None:
         from PIL import Image
-        filename_mtl = filename[:-4] + '.mtl'
-        filename_texture = filename[:-4] + '.png'
-        material_name = 'material_1'
-        texture_image, vertices_textures = create_texture_image(textures)
-        Image.fromarray((np.clip(texture_image, 0, 1) * 255).round().astype(np.uint8)).save(filename_texture)
-    faces = faces.detach().cpu().numpy()
-    with open(filename, 'w') as f:
-        f.write('# %s\n#\n\n' % os.path.basename(filename))
-        if textures is not None:
-            f.write('mtllib %s\n\n' % os.path.basename(filename_mtl))
-        for vertex in vertices.detach().cpu().numpy():
-            f.write('v %.8f %.8f %.8f\n' % (vertex[0], vertex[1], vertex[2]))
-        f.write('\n')
-        if textures is not None:
-            for vertex in vertices_textures.reshape((-1, 2)):
-                f.write('vt %.8f %.8f\n' % (vertex[0], vertex[1]))
-            f.write('\nusemtl %s\n' % material_name)
-            for i, face in enumerate(faces):
-                f.write('f %d/%d %d/%d %d/%d\n' % (face[0] + 1, 3 * i + 1, face[1] + 1, 3 * i + 2, face[2] + 1, 3 * i + 3))
-            f.write('\n')
-        else:
-            for face in faces:
-                f.write('f %d %d %d\n' % (face[0] + 1, face[1] + 1, face[2] + 1))
-    if textures is not None:
-        with open(filename_mtl, 'w') as f:
-            f.write('newmtl %s\n' % material_name)
-            f.write('map_Kd %s\n' % os.path.basename(filename_texture))
+        atlas, vt = create_texture_image(textures)
+        Image.fromarray((np.clip(atlas, 0, 1) * 255).round().astype(np.uint8)).save(stem + '.png')
+        with open(stem + '.mtl', 'w') as fh:
+            fh.write('newmtl %s\nmap_Kd %s\n' % (_MATERIAL, os.path.basename(stem + '.png')))
+    with open(filename, 'w') as fh:
+        fh.write(_obj_text(os.path.basename(filename), vertices.detach().cpu().numpy(), faces.detach().cpu().numpy(), vt,
+                           os.path.basename(stem + '.mtl')))
