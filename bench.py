@@ -269,7 +269,7 @@ def main():
                                                '(VALU / latency bound); the HBM figure is given for completeness')
         def timed(p):
             def st(s):
-                lo = s * V
+                lo = (s % (args.steps + args.warmup)) * V
                 sl = slice(lo, lo + V)
                 return p.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
             for s in range(2):
