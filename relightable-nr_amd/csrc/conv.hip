@@ -95,15 +95,17 @@ template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 __global__ void __launch_bounds__(CTHREADS)
 conv_mfma_kernel(const ConvParams P) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
+    // LDS images as in conv_halo_kernel: [4 planes g][rows | columns][4 floats e], channel k -> g = 2*(k&1) + (k>>3),
+    // e = (k>>1)&3: an MFMA lane reads its 8 channels of a row / column as two lane-consecutive float4s
+    constexpr int ACH = 16 * BM, BCH = 16 * BN;
     constexpr int RPT = BM / 64;
-    constexpr int BQ = BK * BN / 4;                       // float4 slots of a B tile
+    constexpr int BQ = 4 * BN;                            // float4 slots of a B tile: (plane, column)
     constexpr int BPT = (BQ + CTHREADS - 1) / CTHREADS;
     constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
     static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    __shared__ __attribute__((aligned(16))) float As[2][ACH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BCH];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -191,19 +193,15 @@ conv_mfma_kernel(const ConvParams P) {
             }
             areg[p] = v;
         }
-        // packed weights are plane images per chunk, [4 g][wstride][4 e] (see conv_halo_kernel / pack_weight_kernel)
+        // packed weights are plane images per chunk, [4 g][wstride][4 e]: a (plane, column) float4 is copied as it is
         const float* wchunk = P.weight + ((size_t)(par * TAPS + tp) * P.chunks_per_tap + ch) * (16 * (size_t)P.wstride);
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
             const int idx = tid + CTHREADS * b;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < BQ) {
-                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
-                const int col = n0 + 4 * c4;
-                if (col < P.c_out_pad) {
-                    const float* wp = wchunk + ((size_t)(2 * (kr & 1) + (kr >> 3)) * P.wstride + col) * 4 + ((kr >> 1) & 3);
-                    w = make_float4(wp[0], wp[4], wp[8], wp[12]);
-                }
+                const int g = idx / BN, c = idx - g * BN;
+                if (n0 + c < P.c_out_pad) w = *reinterpret_cast<const float4*>(wchunk + ((size_t)g * P.wstride + n0 + c) * 4);
             }
             breg[b] = w;
         }
@@ -213,19 +211,14 @@ conv_mfma_kernel(const ConvParams P) {
 #pragma unroll
         for (int p = 0; p < RPT; p++) {
             const int r = (tid >> 2) + 64 * p;
-            float* a = &As[buf][(4 * q) * LDA + r];
-            a[0 * LDA] = areg[p].x;
-            a[1 * LDA] = areg[p].y;
-            a[2 * LDA] = areg[p].z;
-            a[3 * LDA] = areg[p].w;
+            float* a = &As[buf][((q >> 1) * BM + r) * 4 + 2 * (q & 1)];
+            *reinterpret_cast<float2*>(a) = make_float2(areg[p].x, areg[p].z);                 // channels 4q, 4q+2
+            *reinterpret_cast<float2*>(a + 2 * BM * 4) = make_float2(areg[p].y, areg[p].w);    // channels 4q+1, 4q+3
         }
 #pragma unroll
         for (int b = 0; b < BPT; b++) {
             const int idx = tid + CTHREADS * b;
-            if (idx < BQ) {
-                const int kr = idx / (BN / 4), c4 = idx - kr * (BN / 4);
-                *reinterpret_cast<float4*>(&Bs[buf][kr * LDB + 4 * c4]) = breg[b];
-            }
+            if (idx < BQ) *reinterpret_cast<float4*>(&Bs[buf][idx * 4]) = breg[b];
         }
     };
 
@@ -246,21 +239,22 @@ conv_mfma_kernel(const ConvParams P) {
         const int buf = (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
         if (more) load_regs(kt + 1);
-        const float* a_s = &As[buf][wm0 + l31];
-        const float* b_s = &Bs[buf][wn0 + l31];
+        const float* a_s = &As[buf][((2 * h) * BM + wm0 + l31) * 4];
+        const float* b_s = &Bs[buf][((2 * h) * BN + wn0 + l31) * 4];
 #pragma unroll
-        for (int s = 0; s < BK / 2; s++) {
-            const int k = 2 * s + h;
-            float a[WM], b[WN];
+        for (int sg = 0; sg < 2; sg++) {
+            floatx4 a4[WM], b4[WN];
 #pragma unroll
-            for (int i = 0; i < WM; i++) a[i] = a_s[k * LDA + 32 * i];
+            for (int i = 0; i < WM; i++) a4[i] = *reinterpret_cast<const floatx4*>(a_s + (sg * BM + 32 * i) * 4);
 #pragma unroll
-            for (int j = 0; j < WN; j++) b[j] = b_s[k * LDB + 32 * j];
+            for (int j = 0; j < WN; j++) b4[j] = *reinterpret_cast<const floatx4*>(b_s + (sg * BN + 32 * j) * 4);
 #pragma unroll
-            for (int i = 0; i < WM; i++)
+            for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int j = 0; j < WN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < WM; i++)
+#pragma unroll
+                    for (int j = 0; j < WN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], b4[j][e], acc[i][j], 0, 0, 0);
         }
         if (more) store_lds(buf ^ 1);
         __syncthreads();
