@@ -419,8 +419,8 @@ conv_halo_kernel(const ConvParams P) {
     const int trem = mt_ - n * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 
-    // halo slots of this thread: fixed source pixels for the whole K loop.  Slots past the halo repeat an earlier slot
-    // (same value to the same LDS address), the zero border of the transposed conv is a 0/1 factor: no branches.
+    // halo slots of this thread: fixed source pixels for the whole K loop.  Slots past the halo fetch a valid address
+    // (an earlier slot's) and are never stored; the zero border of the transposed conv is a 0/1 factor.
     const int q = tid & 3;
     unsigned spix[APT];      // pixel index inside the view
     int sdst[APT];           // float index of the (x, z) pair inside a chunk image; the (y, w) pair is 2 planes on
@@ -534,7 +534,8 @@ conv_halo_kernel(const ConvParams P) {
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
 #pragma unroll
-        for (int j = 0; j < APT; j++) store_a(cs, load_a(cs, j), j, 0);
+        for (int j = 0; j < APT; j++)
+            if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j, 0);
         dma_b(c_begin, 0, 0);
     }
     __syncthreads();
@@ -604,7 +605,7 @@ conv_halo_kernel(const ConvParams P) {
 #pragma unroll
                 for (int u = 0; u < APS; u++) {
                     const int j = t * APS + u;
-                    if (next_chunk && j < APT) store_a(csn, av[u], j, abuf ^ 1);
+                    if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[u], j, abuf ^ 1);
                 }
             }
 #endif
@@ -617,7 +618,8 @@ conv_halo_kernel(const ConvParams P) {
         }
         if (ABUFS == 1 && next_chunk) {     // every wave is past the last tap's reads: swap the next halo in
 #pragma unroll
-            for (int j = 0; j < APT; j++) store_a(csn, av_all[j], j, 0);
+            for (int j = 0; j < APT; j++)
+                if (tid + CTHREADS * j < ASLOTS) store_a(csn, av_all[j], j, 0);
             __syncthreads();
         }
     }
