@@ -147,24 +147,24 @@ def main():
     ids = (np.arange(n_total) * 7) % 720
     allv = scene.spiral_views(args.img_size, ids)
     poses = {k: torch.from_numpy(v).to(dev) for k, v in allv.items()}
-    gathered = [torch.empty(world * V, 3, args.img_size, args.img_size, device=dev) for _ in range(2)] if use_dist else None
-    pending = []
+    # frames over xGMI — the only exchange of the path, issued asynchronously so that the gather of step s overlaps the
+    # rendering of step s+1 (rnr_amd.dist.OverlappedFrameGather; the pipeline alternates two frame buffers)
+    gather = None
+    if use_dist:
+        from rnr_amd.dist import OverlappedFrameGather
+        gather = OverlappedFrameGather(world, (V, 3, args.img_size, args.img_size), torch.float32, dev)
 
     def step(s):
         lo = (s * world + rank) * V
         sl = slice(lo, lo + V)
         img = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
         if use_dist:
-            # frames over xGMI — the only exchange of the path.  Issued asynchronously (RCCL's own stream) so that the
-            # gather of step s overlaps the rendering of step s+1; frame / gather buffers are double-buffered.
-            pending.append(dist.all_gather_into_tensor(gathered[s & 1], img, async_op=True))
-            if len(pending) > 1:
-                pending.pop(0).wait()
+            gather.submit(img)
         return img
 
     def drain():
-        while pending:
-            pending.pop(0).wait()
+        if use_dist:
+            gather.drain()
 
     for s in range(args.warmup):
         step(s)

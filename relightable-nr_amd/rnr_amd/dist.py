@@ -51,6 +51,46 @@ def render_views_sharded(render_fn, views, group=None, gather=True):
     return torch.cat(pieces, 0)
 
 
+class OverlappedFrameGather:
+    """The all-gather of step k issued asynchronously so that it overlaps the rendering of step k+1 (RCCL runs it on its
+    own stream over xGMI).  `depth` gather buffers are used in turn; `submit` retires the oldest gather before a buffer
+    is reused, so a caller that alternates `depth` frame buffers of its own (RNRPipeline does, with two) never has a
+    frame overwritten while it is still being sent.
+
+        g = OverlappedFrameGather(world, frames.shape, frames.dtype, frames.device)
+        for poses in steps:
+            g.submit(pipe.render(*poses))      # returns at once
+        all_frames = g.drain()                 # [world * b, ...] of the last step
+    """
+
+    def __init__(self, world_size, frames_shape, dtype, device, group=None, depth=2):
+        self.group, self.depth = group, int(depth)
+        shape = (int(world_size) * int(frames_shape[0]),) + tuple(int(x) for x in frames_shape[1:])
+        self.buffers = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.pending = []          # (work, buffer), oldest first
+        self.submitted = 0
+        self.latest = None         # buffer of the most recently completed gather
+
+    def submit(self, frames):
+        buf = self.buffers[self.submitted % self.depth]
+        work = dist.all_gather_into_tensor(buf, frames, group=self.group, async_op=True)
+        self.pending.append((work, buf))
+        self.submitted += 1
+        while len(self.pending) >= self.depth:
+            self._retire()
+        return self.latest
+
+    def _retire(self):
+        work, buf = self.pending.pop(0)
+        work.wait()
+        self.latest = buf
+
+    def drain(self):
+        while self.pending:
+            self._retire()
+        return self.latest
+
+
 def _dev(views):
     return next(iter(views.values())).device
 

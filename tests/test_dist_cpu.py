@@ -56,6 +56,51 @@ def test_sharded_render_gloo(B):
     assert bounds[0][0] == 0 and bounds[-1][1] == B and bounds[0][1] == bounds[1][0]
 
 
+def _worker_overlap(rank, world, port, steps, q):
+    sys.path.insert(0, os.path.join(ROOT, 'relightable-nr_amd'))
+    from rnr_amd import dist as rdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        b = 3
+        frame = lambda s, r: torch.full((b, 2, 4, 4), float(100 * s + r)) + torch.arange(b, dtype=torch.float32)[:, None, None, None]
+        g = rdist.OverlappedFrameGather(world, (b, 2, 4, 4), torch.float32, 'cpu')
+        mine = [torch.empty(b, 2, 4, 4) for _ in range(2)]          # two frame buffers used in turn, like RNRPipeline
+        ok, seen = True, []
+        for s in range(steps):
+            buf = mine[s % 2]
+            buf.copy_(frame(s, rank))
+            done = g.submit(buf)
+            if done is not None:                                     # the gather of step s-1 has completed
+                want = torch.cat([frame(s - 1, r) for r in range(world)], 0)
+                ok = ok and torch.equal(done, want)
+                seen.append(s - 1)
+        last = g.drain()
+        ok = ok and torch.equal(last, torch.cat([frame(steps - 1, r) for r in range(world)], 0))
+        q.put((rank, bool(ok), seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_frame_gather_gloo():
+    """The asynchronous, double-buffered frame all-gather bench.py uses for N > 1: every step's frames arrive intact and
+    in order although step s+1 overwrites the other frame buffer while the gather of step s is in flight."""
+    world, steps = 2, 5
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000) + 77
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(seen == list(range(steps - 1)) for _, _, seen in res), res
+
+
 def test_shard_bounds_properties():
     sys.path.insert(0, os.path.join(ROOT, 'relightable-nr_amd'))
     from rnr_amd.dist import shard_bounds
