@@ -105,13 +105,20 @@ void ref_backward_depth_map(const float* faces, const float* depth_map, const in
 }
 '''
 
-_lib = None
+_libs = {}
+
+# How the reference itself is compiled: neural_renderer/setup.py:14-27 passes no flags to nvcc, whose default is
+# --fmad=true (a*b+c contracted into one fused multiply-add wherever the compiler sees it).  The committed fixtures
+# are generated WITHOUT contraction (bit-reproducible on any host); the `fma=True` build contracts like nvcc does
+# (`-ffp-contract=fast -mfma`) and is used to show that the integer outputs do not depend on that choice
+# (make_golden.gen_raster_fma, DESIGN.md §3.1).
+FLAGS = {False: ['-ffp-contract=off'], True: ['-ffp-contract=fast', '-mfma']}
 
 
-def build():
-    global _lib
-    if _lib is not None:
-        return _lib
+def build(fma=False):
+    fma = bool(fma)
+    if fma in _libs:
+        return _libs[fma]
     tmp = tempfile.mkdtemp(prefix='rnr_ref_kernels_')
     with open(REF_CU) as fh:
         body = fh.readlines()[FIRST - 1:LAST]
@@ -121,19 +128,22 @@ def build():
         fh.writelines(body)
         fh.write(_SHIM_TAIL)
     so = os.path.join(tmp, 'ref_kernels.so')
-    subprocess.check_call(['g++', '-O2', '-ffp-contract=off', '-fopenmp', '-shared', '-fPIC', '-w',
-                           src, '-o', so])
-    _lib = ctypes.CDLL(so)
-    return _lib
+    subprocess.check_call(['g++', '-O2'] + FLAGS[fma] + ['-fopenmp', '-shared', '-fPIC', '-w', src, '-o', so])
+    if fma:
+        # the build must really contain fused multiply-adds, otherwise the comparison proves nothing
+        dis = subprocess.run(['objdump', '-d', so], capture_output=True, text=True).stdout
+        assert 'vfmadd' in dis or 'vfnmadd' in dis or 'vfmsub' in dis, 'FMA build holds no fused instruction'
+    _libs[fma] = ctypes.CDLL(so)
+    return _libs[fma]
 
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def face_index_map(faces, image_size, near, far, return_depth=1):
+def face_index_map(faces, image_size, near, far, return_depth=1, fma=False):
     """faces [B,nf,3,3] float32 -> dict of the kernel outputs (UNFLIPPED, as the extension returns)."""
-    lib = build()
+    lib = build(fma)
     faces = np.ascontiguousarray(faces, np.float32)
     B, nf = faces.shape[:2]
     S = image_size

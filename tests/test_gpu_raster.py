@@ -48,6 +48,39 @@ def test_golden_bit_exact(golden, name):
     assert_same(r, g)
 
 
+FMA_CASES = ['raster_soup64', 'raster_soup50', 'raster_soup64_nearfar', 'raster_sphere128']
+
+
+@pytest.mark.parametrize('name', FMA_CASES)
+def test_index_map_equals_fma_contracted_reference(golden, name):
+    """The reference is compiled by nvcc with --fmad=true (neural_renderer/setup.py:14-27 passes no flags); the
+    `_fma` fixtures are its kernel bodies built with -ffp-contract=fast -mfma.  The HIP index map (built without
+    contraction) must equal that one too; float maps are allowed the drift the two reference builds show between
+    themselves (recorded in the fixture)."""
+    g, gf = golden(name), golden(name + '_fma')
+    assert int(gf['index_flips']) == 0                      # the two reference builds agree on every pixel
+    r = run_hip_raster(g['faces'], int(g['image_size']), float(g['near']), float(g['far']))
+    assert np.array_equal(r['face_index_map'], gf['face_index_map_fma'])
+    cov = r['face_index_map'] >= 0
+    ok = np.isfinite(gf['weight_map_fma']).all(-1) & np.isfinite(r['weight_map']).all(-1) & cov
+    assert np.abs(r['weight_map'][ok] - gf['weight_map_fma'][ok]).max() <= 2 * float(gf['weight_abs_max']) + 1e-7
+
+
+def test_sphere512_index_map_equals_both_reference_builds(golden):
+    """Bench workload (65 536-face sphere, 512^2, spiral view 37): projected vertices come from the fixture (reference
+    projection.py run in the build container), so nothing depends on this host's libm/matmul; the HIP index map must
+    equal the reference kernel's under BOTH contraction modes."""
+    from rnr_amd import scene
+    gf = golden('raster_sphere512_fma')
+    assert int(gf['index_flips']) == 0
+    assert np.array_equal(gf['face_index_map_nofma'], gf['face_index_map_fma'])
+    idx = scene.uv_sphere(128, 256)['f_v_idx']
+    faces = gf['v_uvz'][:, idx.astype(np.int64)]            # vertices_to_faces.py:4-46
+    r = run_hip_raster(faces, 512, 0.0, 1e5)
+    assert np.array_equal(r['face_index_map'], gf['face_index_map_fma'])
+    assert 0.4 < (r['face_index_map'] >= 0).mean() < 0.7
+
+
 @pytest.mark.parametrize('S,nf,seed', [(17, 50, 1), (96, 3000, 2), (256, 20000, 3), (33, 1, 4)])
 def test_random_soup_vs_oracle(S, nf, seed):
     """Ragged sizes, many overlapping faces, slivers and far-away faces, batch of 2."""
@@ -317,6 +350,23 @@ def test_gbuffer_vs_reference_module(golden):
             if k == 'uv_map':
                 d = np.minimum(d, 1.0 - d)
             assert d.max() < tol * max(1.0, np.abs(ref[ok]).max()), (k, d.max())
+    # (C) the reference's own projected vertices (fixture `v_uvz`, 13th element of the 14-tuple, network.py:216) fed to the
+    # HIP kernel: no host matmul in between, so the integer maps must equal the reference golden EXACTLY and the
+    # interpolated maps to float rounding (pointwise three-term sums in a different association)
+    for i in range(2):
+        v_ref = torch.from_numpy(g['view%d_v_uvz' % i]).contiguous().to(dev)
+        gb = ops.rasterize_gbuffer(mesh, v_ref, pose[i:i + 1].to(dev), S)
+        torch.cuda.synchronize()
+        c = lambda k: gb[k][0].cpu().numpy()
+        assert np.array_equal(c('face_index_map'), g['view%d_face_index_map' % i][0])
+        assert np.array_equal(c('alpha'), g['view%d_alpha' % i][0])
+        for k, tol in [('uv_map', 2e-6), ('normal_map', 2e-6), ('normal_map_cam', 2e-6), ('position_map', 2e-6),
+                       ('position_map_cam', 4e-6), ('depth', 2e-6), ('weight_map', 2e-6)]:
+            ref = g['view%d_%s' % (i, k)][0]
+            d = np.abs(c(k).reshape(ref.shape) - ref)
+            if k == 'uv_map':
+                d = np.minimum(d, 1.0 - d)
+            assert d.max() <= tol * max(1.0, np.abs(ref).max()), (k, d.max())
     # HIP projection kernel vs the oracle's (well-conditioned vertices)
     v_hip = ops.project_vertices(mesh.v, proj.to(dev), pose[:, :3, :3].contiguous().to(dev),
                                  pose[:, :3, 3].contiguous().to(dev), S)
