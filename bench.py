@@ -47,6 +47,14 @@ def parse():
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
                     help="conv arithmetic of the timed loop: exact fp32 MFMA (default, the headline) or fp32 emulated on the bf16 "
                          "matrix cores (RNR_CONV_F32_EMU_BF16X6)")
+    ap.add_argument('--pmc-file', default=None,
+                    help='merged.json written by scripts/pmc.sh (rocprofv3 --pmc passes over THIS command line at the same '
+                         '--views-per-step / --precision): source of roofline.traffic.  Without it the newest committed '
+                         'profiles/r*_pmc_per_kernel_*.json recorded at the same batch size and precision is used and the '
+                         'field is labelled traffic_from_committed_profile')
+    ap.add_argument('--check-gather', action='store_true',
+                    help='after the timed loop verify on every rank that its slot of the gathered frame buffer equals the '
+                         'frames it rendered (bitwise) and report it as gather_check (tests/test_gpu_dist.py)')
     ap.add_argument('--main-loop-only', action='store_true',
                     help='skip the per-stage and single-view extras after the timed loop (rocprofv3 runs: every kernel launch in the profile then belongs to a timed or warm-up step)')
     return ap.parse_args()
@@ -67,33 +75,62 @@ def build_scene(args):
     }
 
 
-def cpu_baseline(sc, args, view_id, hip_image, emu_image=None):
-    """The oracle (a port of the reference's algorithm) timed on this box's host cores on ONE frame of the same
-    workload; also yields the parity figure (PSNR of the HIP frame vs the oracle frame)."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(sc, args, view_id, hip_image, emu_image=None, budget_s=30.0):
+    """The oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample of the same
+    workload (BASELINE.md §3 protocol: warm-up, then >= 5 timed frames, median; pose tensors and the view-independent
+    lmax-10 lighting basis are prepared OUTSIDE the timer — the reference builds that basis once in LightingSH.__init__,
+    network.py:574-582); also yields the parity figure (PSNR of the HIP frame vs the oracle frame of the same pose)."""
     from oracle import rnr_oracle as orc
     from oracle import raster as oras
     from rnr_amd import scene
     oras.build()
-    cores = min(os.cpu_count() or 1, 32)      # more threads only oversubscribe the small torch-CPU ops
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 32)      # more threads only oversubscribe the small torch-CPU ops
     torch.set_num_threads(cores)
     try:
-        import ctypes
         ctypes.CDLL('libgomp.so.1').omp_set_num_threads(cores)
     except OSError:
         pass
     mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
-    n_frames = 2                                   # bounded sample: ~10 s of host work
-    t0 = time.time()
-    for vid in [(view_id + 360) % 720, view_id][-n_frames:]:      # the LAST one is the frame the HIP path rendered last
-        views = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [vid]).items()}
-        basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))      # init-time in the reference
+    n_timed = 5
+    vids = [(view_id + 97 * (k + 1)) % 720 for k in range(n_timed)] + [view_id]   # the LAST one is the frame the HIP path rendered last
+    views_all = [{k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size, [vid]).items()} for vid in vids]
+
+    def frame(views):
         lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]                   # network.py:622-627, per view
-        ref = orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'],
-                               sc['pivots_diff'])
-    dt = (time.time() - t0) / n_frames
-    out = {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-           'sample': '%d frames %dx%d, same scene/weights (oracle: OpenMP C rasterizer + torch-CPU fp32 shading/U-Net), %.1f s per frame'
-                     % (n_frames, args.img_size, args.img_size, dt)}
+        return orc.render_frame(mesh_t, views, args.img_size, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'],
+                                sc['pivots_diff'])
+    t0 = time.time()
+    frame(views_all[0])                                                           # warm-up (thread pools, allocator)
+    warm = time.time() - t0
+    times = []
+    ref = None
+    for i, views in enumerate(views_all[1:]):
+        # bounded sample: stop early once the budget is spent, but always render the parity frame (the last one)
+        last = i == len(views_all) - 2
+        if not last and sum(times) + warm > budget_s:
+            continue
+        t0 = time.time()
+        ref = frame(views)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    out = {'value': 1.0 / med, 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+           'host_logical_cpus': ncpu, 'seconds_per_frame_median': med, 'timed_frames': len(times), 'warmup_frames': 1,
+           'sample': '1 warm-up + %d timed frames %dx%d (median), same scene/weights as the GPU run, one view per call like '
+                     'test_rnr.py:265 (oracle: OpenMP C rasterizer + torch-CPU fp32 shading/U-Net on %d threads); pose '
+                     'tensors and the lmax-10 lighting basis prepared outside the timer'
+                     % (len(times), args.img_size, args.img_size, cores)}
     parity = None
     if hip_image is not None:
         parity = {'psnr_db_vs_oracle': orc.psnr(hip_image.cpu(), ref['image']),
@@ -104,20 +141,41 @@ def cpu_baseline(sc, args, view_id, hip_image, emu_image=None):
     return out, parity
 
 
-def pmc_traffic_per_step(views_per_step):
-    """HBM-side bytes of the conv kernels per step from the committed rocprofv3 PMC passes (profiles/README.md):
-    (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, scaled from the
-    profiled 4 views/step to this run's batch.  None if no profile is committed."""
+def pmc_traffic_per_step(args):
+    """HBM-side bytes of the conv kernels per step from rocprofv3 PMC passes (profiles/README.md):
+    (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950.  PMC passes
+    serialise kernels and cannot run inside a timed bench run, so the counters come from a separate run of the SAME
+    command line (scripts/pmc.sh): either the file given by --pmc-file or the newest committed profile whose recorded
+    batch size / precision / image size equal this run's.  Never rescaled from another batch size.
+    Returns (bytes per step | None, info dict)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel_*views4.json')))
-    if not files:
-        return None, None
-    prof = json.load(open(files[-1]))
-    steps = 3       # the PMC runs use --steps 2 --warmup 1
-    kb = sum(2.0 * v.get('FETCH_SIZE_total', 0.0) + v.get('WRITE_SIZE_total', 0.0) for k, v in prof.items() if 'conv_' in k)
-    if kb <= 0:
-        return None, None
-    return kb * 1024.0 / steps * (views_per_step / 4.0), os.path.basename(files[-1])
+    V = args.views_per_step
+    cands = [args.pmc_file] if args.pmc_file else sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel_*.json')))[::-1]
+    for f in cands:
+        try:
+            prof = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        meta = prof.get('_meta')
+        if meta is None:        # round-1 files carry no meta block: their name states the batch size, f32 unless tagged
+            import re
+            mv = re.search(r'views(\d+)', os.path.basename(f))
+            ms = re.search(r'steps(\d+)', os.path.basename(f))
+            meta = {'views_per_step': int(mv.group(1)) if mv else -1, 'steps': int(ms.group(1)) if ms else 2, 'warmup': 1,
+                    'precision': 'bf16x6' if 'bf16x6' in os.path.basename(f) else 'f32', 'img_size': 512}
+        if (meta['views_per_step'], meta['precision'], meta.get('img_size', 512)) != (V, args.precision, args.img_size):
+            continue
+        steps = meta['steps'] + meta['warmup']
+        kb = sum(2.0 * v.get('FETCH_SIZE_total', 0.0) + v.get('WRITE_SIZE_total', 0.0)
+                 for k, v in prof.items() if k.startswith('conv_') or 'conv_' in k.split('(')[0])
+        if kb <= 0:
+            continue
+        return kb * 1024.0 / steps, {'traffic_source': os.path.basename(f),
+                                     'traffic_from_committed_profile': not bool(args.pmc_file),
+                                     'traffic_profile': meta}
+    return None, {'traffic_source': None, 'traffic_from_committed_profile': False,
+                  'traffic_note': 'no PMC profile recorded at views_per_step=%d precision=%s: run scripts/pmc.sh and pass '
+                                  '--pmc-file' % (V, args.precision)}
 
 
 def main():
@@ -199,6 +257,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pipe.unet.forward = orig_forward
+    gather_check = None
+    if args.check_gather and use_dist:
+        got = gather.latest[rank * V:(rank + 1) * V]
+        bad = torch.tensor([0 if torch.equal(got, img) else 1, int(gather.latest.shape[0] != world * V)], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        gather_check = {'ok': int(bad.sum().item()) == 0, 'ranks_with_mismatch': int(bad[0].item()),
+                        'gathered_shape': list(gather.latest.shape), 'backend': dist.get_backend()}
     last_frame = img[V - 1:V].clone()       # the frame buffers are reused by the extra renders below
     emu_last = None
     if use_dist:
@@ -217,28 +282,32 @@ def main():
     achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic_per_step(V)
+        traffic, traffic_info = pmc_traffic_per_step(args)
         res = {
             'metric': 'rendered frames/sec at %dx%d (material_sphere-like synthetic scene), full HIP RNR path'
                       % (args.img_size, args.img_size),
             'value': args.steps * world * V / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: test_rnr.py spiral_step720 views, %dx%d, full HIP RenderingNet '
+            'config': {'workload': 'BASELINE configs[2] in %d-view batches (the reference renders 1 view per call; that mode is '
+                                   'reported as single_view_mode): test_rnr.py spiral_step720 views, %dx%d, full HIP RenderingNet '
                                    '(f32 MFMA convs + SH relight), UV-sphere 65536 faces, neural texture 512^2 x %d ch x 4 '
-                                   'levels, U-Net %d->%d nf0=%d' % (args.img_size, args.img_size, args.tex_ch, sc['c_in'],
+                                   'levels, U-Net %d->%d nf0=%d' % (V, args.img_size, args.img_size, args.tex_ch, sc['c_in'],
                                                                    3 * sc['n_rays'], args.nf0),
                        'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (%d conv launches/step; HIP events bracket the U-Net stage incl. bn_finalize + split-K reduce)' % n_conv,
                          'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/step (HBM-side, PMC)',
-                         'traffic_source': traffic_src,
+                         'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
+                         **traffic_info,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
                          'out_layer_tiles_skipped': skipped,
                          'flops_note': 'executed FLOPs = %.1f GFLOP/view live U-Net minus the out-layer pixel tiles that hold no '
                                        'foreground pixel when --tile-skip is given (never read: the ray renderer zeroes background)'
                                        % (pipe.unet.flops_per_view / 1e9)},
         }
+        if gather_check is not None:
+            res['gather_check'] = gather_check
         extras = not args.main_loop_only
         # per-stage HIP events (5 extra steps outside the timed region): the non-conv stages against the HBM roofline
         P_px = args.img_size * args.img_size

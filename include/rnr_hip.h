@@ -292,6 +292,15 @@ int rnr_bn_finalize(const double* stats, const float* gamma, const float* beta, 
 int rnr_bn_finalize_reset(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
                     int num_views, int channels, int c_pad, double count, float eps, void* stream);
 
+/* Whole-batch variant: torch's train-mode BatchNorm2d reduces over (N,H,W) of the call (the reference forces that mode
+ * at inference, test_rnr.py:229-233; with its N = 1 per call the two coincide).  The per-view partial sums of
+ * rnr_conv2d are added over the `num_views` views (count = num_views * count_per_view), the same scale/shift is
+ * written to every view, and — when the pointers are non-NULL — running_mean / running_var [channels] are updated as
+ * torch does: running = (1 - momentum) * running + momentum * {mean, UNBIASED variance}.  Resets stats to zero. */
+int rnr_bn_finalize_batch(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
+                          float* running_mean, float* running_var, float momentum, int num_views, int channels,
+                          int c_pad, double count_per_view, float eps, void* stream);
+
 /* Layout helpers for the drop-in RenderingNet.forward (NCHW in / NCHW out). */
 int rnr_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream);
 /* out[n,c,h,w] = f(in[n,h,w,c] + bias[c]) with bias optional (NULL) and f = tanhf when apply_tanh != 0 */

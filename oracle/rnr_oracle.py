@@ -92,7 +92,7 @@ def rasterize_rgbad(faces_v, image_size, near, far):
 
 
 def rasterizer_forward(mesh, proj, pose, img_size, dist_coeffs=None, offset=None, scale=None,
-                       near=0.0, far=1e5):
+                       near=0.0, far=1e5, v_uvz_ndc=None):
     """network.Rasterizer.forward, network.py:156-216 (+ renderer.py:207-257).
 
     mesh: dict of torch tensors v [nv,3], vt [nvt,2], vn [nvn,3], f_v_idx/f_vt_idx/f_vn_idx [nf,3] int32
@@ -106,7 +106,9 @@ def rasterizer_forward(mesh, proj, pose, img_size, dist_coeffs=None, offset=None
     verts = mesh['v'][None]
     R = pose[:, :3, :3]
     t = pose[:, :3, 3][:, None, :]
-    v_uvz = projection(verts.expand(N, -1, -1), proj, R, t, dist_coeffs, S, offset, scale)
+    # v_uvz_ndc: projected vertices computed elsewhere (e.g. by the kernel under test), so that the integer maps can be
+    # compared exactly without this host's matmul rounding in between
+    v_uvz = projection(verts.expand(N, -1, -1), proj, R, t, dist_coeffs, S, offset, scale) if v_uvz_ndc is None else v_uvz_ndc
     faces_v_uvz = gather_faces(v_uvz, mesh['f_v_idx'][None])
     ras = rasterize_rgbad(faces_v_uvz, S, near, far)
     fim, depth, alpha = ras['face_index_map'], ras['depth'], ras['alpha']

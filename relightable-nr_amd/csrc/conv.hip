@@ -1119,6 +1119,45 @@ bn_finalize_kernel(double* __restrict__ stats, const float* __restrict__ gamma, 
     if (RESET) { stats[2 * (size_t)i + 0] = 0.0; stats[2 * (size_t)i + 1] = 0.0; }
 }
 
+// Whole-batch statistics (torch's train-mode BatchNorm2d over (N,H,W), pytorch_prototyping.py via nn.BatchNorm2d):
+// one lane per channel sums the per-view partial sums, writes the same scale/shift to every view and optionally
+// updates running_mean / running_var (momentum m, UNBIASED variance, as torch does).  Always resets stats.
+__global__ void __launch_bounds__(256)
+bn_finalize_batch_kernel(double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                         float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ running_mean,
+                         float* __restrict__ running_var, float momentum, int nviews, int channels, int c_pad,
+                         double count_per_view, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c_pad) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < nviews; n++) {
+        const size_t i = (size_t)n * c_pad + c;
+        s1 += stats[2 * i + 0];
+        s2 += stats[2 * i + 1];
+        stats[2 * i + 0] = 0.0;
+        stats[2 * i + 1] = 0.0;
+    }
+    float sc = 0.f, sh = 0.f;
+    if (c < channels) {
+        const double count = count_per_view * (double)nviews;
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double s = (double)gamma[c] / sqrt(var + (double)eps);
+        sc = (float)s;
+        sh = (float)((double)beta[c] - mean * s);
+        if (running_mean) running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        if (running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        }
+    }
+    for (int n = 0; n < nviews; n++) {
+        scale[(size_t)n * c_pad + c] = sc;
+        shift[(size_t)n * c_pad + c] = sh;
+    }
+}
+
 __host__ __device__ __forceinline__ int weight_row_stride(int c_out_pad) { return (c_out_pad + 127) / 128 * 128; }
 
 // value of the (parity, tap, padded input channel c, output column co) entry of the implicit-GEMM weight matrix
@@ -1477,4 +1516,15 @@ extern "C" int rnr_bn_finalize(const double* stats, const float* gamma, const fl
 extern "C" int rnr_bn_finalize_reset(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
                                      int num_views, int channels, int c_pad, double count, float eps, void* stream) {
     return bn_finalize_impl(stats, gamma, beta, scale, shift, num_views, channels, c_pad, count, eps, true, stream);
+}
+
+extern "C" int rnr_bn_finalize_batch(double* stats, const float* gamma, const float* beta, float* scale, float* shift,
+                                     float* running_mean, float* running_var, float momentum, int num_views,
+                                     int channels, int c_pad, double count_per_view, float eps, void* stream) {
+    RNR_REQUIRE(stats && gamma && beta && scale && shift, "rnr_bn_finalize_batch: null pointer argument");
+    RNR_REQUIRE(num_views > 0 && channels > 0 && c_pad >= channels && count_per_view > 0, "rnr_bn_finalize_batch: bad sizes");
+    hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3((c_pad + 255) / 256), dim3(256), 0, as_stream(stream), stats, gamma,
+                       beta, scale, shift, running_mean, running_var, momentum, num_views, channels, c_pad, count_per_view,
+                       eps);
+    return check_launch("bn_finalize_batch_kernel");
 }

@@ -113,36 +113,68 @@ class Unet(nn.Module):
                                                   out_channels_gcn=out_channels_gcn, highway_mode=outermost_highway_mode)
         self.out_layer = nn.Sequential(Conv2dSame(2 * nf0, out_channels, kernel_size=3, bias=True))
         self.out_layer_weight = self.out_layer[0].weight
-        self._plans = {}
+        self._plans, self._plan_versions = {}, {}
         self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
 
     def _apply(self, fn, *a, **k):     # .to()/.cuda() moves the weights: plans are rebuilt lazily
-        self._plans = {}
+        self._plans, self._plan_versions = {}, {}
         return super()._apply(fn, *a, **k)
 
+    def _weights_version(self):
+        """Changes whenever a parameter or buffer is modified in place (optimizer step, `.data` assignment, copy_)."""
+        return tuple((id(t), t._version) for t in list(self.parameters()) + [b for n, b in self.named_buffers()
+                                                                             if 'num_batches' not in n])
+
     def _plan(self, n, h, w, device):
-        bn_train = [m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        bn_mods = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        bn_train = [m.training for m in bn_mods]
         if any(m.training for m in self.modules() if isinstance(m, nn.Dropout2d)):
             raise NotImplementedError('Dropout2d in training mode: only inference (module.eval()) is built')
         if len(set(bn_train)) > 1:
             raise NotImplementedError('mixed BatchNorm train/eval modes')
-        mode = 'batch' if (bn_train and bn_train[0]) else 'running'
-        key = (n, h, w, str(device), mode)
-        if key not in self._plans:
+        # train-mode BatchNorm2d reduces over the WHOLE batch of the call (torch semantics; the reference's scripts
+        # call with N = 1, where this equals per-view statistics)
+        mode = 'batch_all' if (bn_train and bn_train[0]) else 'running'
+        key = (h, w, str(device), mode)
+        ver = self._weights_version()
+        plan = self._plans.get(key)
+        # one plan per (size, device, mode), sized for the largest batch seen; rebuilt when a weight changed in place
+        if plan is None or plan.N < n or self._plan_versions.get(key) != ver:
             cin, cout, nf0, nd = self.cfg
             sd = {'net.' + k: v for k, v in self.state_dict().items()}
-            self._plans[key] = UNetPlan(sd, cin, cout, nf0, nd, (h, w), n, device, bn_mode=mode)
-        return self._plans[key]
+            self._plans.pop(key, None)
+            plan = UNetPlan(sd, cin, cout, nf0, nd, (h, w), max(n, plan.N if plan is not None else 0), device, bn_mode=mode,
+                            update_running_stats=(mode == 'batch_all'))
+            self._plans[key] = plan
+            self._plan_versions[key] = ver
+        return plan
+
+    def _live_batchnorms(self):
+        """BatchNorm modules the live path runs through (the `fuse` block of the GCN branch never reaches the output)."""
+        return [m for name, m in self.named_modules() if isinstance(m, nn.BatchNorm2d) and '.fuse.' not in '.' + name + '.']
 
     def forward(self, x, v_fea=None):
         """x [N,Cin,H,W] -> raw out-layer output [N,Cout,H,W] (bias applied).  v_fea is accepted and unused: the
-        reference's GCN branch never reaches the output (pytorch_prototyping.py:407-419)."""
+        reference's GCN branch never reaches the output (pytorch_prototyping.py:407-419).
+
+        BatchNorm semantics follow torch: in train mode (what test_rnr.py:229-233 forces at inference) statistics are
+        taken over the whole [N,H,W] batch of THIS call and running_mean / running_var / num_batches_tracked of the live
+        layers are updated.  Deviation: with use_gcn=True the reference additionally runs the dead GCN pass, which
+        updates the running statistics of `down`/`submodule`/`up`/`fuse` a second time from v_fea-dependent inputs; that
+        pass is not executed here, so those side effects are absent (outputs are unaffected)."""
         return self.forward_fused(x, apply_tanh=False)
 
     def forward_fused(self, x, apply_tanh):
         n, _, h, w = x.shape
         plan = self._plan(n, h, w, x.device)
         raw = plan.forward(ops.nchw_to_nhwc(x.float().contiguous(), plan.in_c_pad))
+        if plan.bn_mode == 'batch_all':
+            # the kernels just updated running_mean / running_var in place: eval-mode plans folded the old values
+            for k in [k for k in self._plans if k[3] == 'running']:
+                del self._plans[k]
+            for m in self._live_batchnorms():
+                if m.num_batches_tracked is not None:
+                    m.num_batches_tracked += 1
         return ops.nhwc_to_nchw(raw, plan.out_channels, bias=plan.out_bias, apply_tanh=apply_tanh)
 
 

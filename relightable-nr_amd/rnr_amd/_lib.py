@@ -78,6 +78,7 @@ SIGNATURES = {
                                   c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'rnr_bn_finalize': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_bn_finalize_reset': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
+    'rnr_bn_finalize_batch': (c_int, [c_void_p] * 7 + [c_float, c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rnr_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'rnr_ray_render': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -107,16 +108,33 @@ class RnrError(RuntimeError):
 
 def _build_from_source():
     """A source checkout without the built library: compile it with hipcc if the ROCm toolchain is there (still the
-    HIP path — there is nothing else to fall back to).  Errors surface in load()."""
+    HIP path — there is nothing else to fall back to).  Safe under torchrun: an exclusive file lock serialises the
+    ranks (the first one builds, the others find the library once they get the lock), the Makefile links to a
+    temporary name and renames it into place.  Returns the captured build log on failure, None otherwise."""
+    import fcntl
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or ('/opt/rocm/bin/hipcc' if os.path.isfile('/opt/rocm/bin/hipcc') else None)
     if hipcc is None:
-        return
+        return 'hipcc not found (PATH, /opt/rocm/bin)'
+    csrc = os.path.join(os.path.dirname(_HERE), 'csrc')
     try:
-        subprocess.check_call(['make', '-C', os.path.join(os.path.dirname(_HERE), 'csrc'), '-s', '-j4', 'HIPCC=' + hipcc])
-    except (subprocess.CalledProcessError, OSError):
-        pass
+        lock = open(os.path.join(csrc, '.build.lock'), 'w')
+    except OSError as e:
+        return 'cannot create build lock in %s: %s' % (csrc, e)
+    with lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.isfile(LIB_PATH):        # another rank built it while we waited
+                return None
+            p = subprocess.run(['make', '-C', csrc, '-s', '-j4', 'HIPCC=' + hipcc], capture_output=True, text=True)
+            if p.returncode != 0:
+                return 'make exited with %d\n%s\n%s' % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+            return None
+        except OSError as e:
+            return 'could not run make: %s' % e
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def load():
@@ -124,11 +142,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
-        _build_from_source()
+    log = None
+    if not os.path.isfile(LIB_PATH) and not os.environ.get('RNR_HIP_LIB'):
+        log = _build_from_source()
     if not os.path.isfile(LIB_PATH):
         raise RnrError('librnr_hip.so not found at %s - build it first: `python -c "import __graft_entry__ as g; '
-                       'g.build()"` or `make -C relightable-nr_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+                       'g.build()"` or `make -C relightable-nr_amd/csrc`. There is no CPU fallback.%s'
+                       % (LIB_PATH, ('\nautomatic build failed: ' + log) if log else ''))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing: fail loudly

@@ -15,12 +15,22 @@ def shard_bounds(num_items, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def render_views_sharded(render_fn, views, group=None, gather=True):
-    """views: dict of per-view tensors with a leading view dimension B (proj, pose, proj_inv, R_inv ...).
+_DTYPE_CODES = [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.uint8, torch.int8, torch.int16,
+                torch.int32, torch.int64, torch.bool]
+
+
+def render_views_sharded(render_fn, views, group=None, gather=True, frame_shape=None, frame_dtype=None):
+    """Convenience helper for ONE batch of views (ragged shards, empty shards, any frame dtype).  The steady-state
+    product path — what bench.py runs — is `RNRPipeline.render` + `OverlappedFrameGather` below (fixed shard size, no
+    shape exchange, gather overlapped with the next step's rendering).
+
+    views: dict of per-view tensors with a leading view dimension B (proj, pose, proj_inv, R_inv ...).
     render_fn(view_slice_dict) -> frames [b, ...] for the local slice (b may be 0).
     Returns frames for ALL B views on every rank (gather=True) or the local slice.
 
     Ragged shards (B not divisible by the world size) are padded to the largest shard for the collective and trimmed.
+    A rank whose shard is empty does not know the frame shape / dtype: unless the caller states them
+    (frame_shape = shape of ONE frame, frame_dtype), they are agreed with one small all_reduce.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -31,16 +41,28 @@ def render_views_sharded(render_fn, views, group=None, gather=True):
     if not gather or world == 1:
         return frames
     max_b = (B + world - 1) // world
-    # every rank needs the frame shape even if its shard is empty
-    shape = torch.zeros(8, dtype=torch.int64, device=_dev(views))
+    if frame_shape is not None and frame_dtype is not None:
+        tail, dtype = tuple(int(x) for x in frame_shape), frame_dtype
+    else:
+        # every rank needs the frame shape AND dtype even if its shard is empty: [ndim, d0..d5, dtype code]
+        meta = torch.zeros(8, dtype=torch.int64, device=_dev(views))
+        if frames is not None:
+            if frames.dim() - 1 > 6 or frames.dtype not in _DTYPE_CODES:
+                raise ValueError('frames of %d dims / dtype %s: pass frame_shape and frame_dtype' % (frames.dim(), frames.dtype))
+            meta[0] = frames.dim() - 1
+            meta[1:frames.dim()] = torch.tensor(frames.shape[1:], dtype=torch.int64)
+            meta[7] = _DTYPE_CODES.index(frames.dtype) + 1
+        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+        meta = meta.tolist()
+        if meta[7] == 0:
+            return None                        # B == 0: nobody rendered anything
+        tail, dtype = tuple(int(x) for x in meta[1:1 + int(meta[0])]), _DTYPE_CODES[int(meta[7]) - 1]
+    if frames is not None and (tuple(frames.shape[1:]) != tail or frames.dtype != dtype):
+        raise ValueError('rank %d renders %s %s, the group agreed on %s %s' % (rank, tuple(frames.shape[1:]), frames.dtype, tail, dtype))
+    send = torch.zeros((max_b,) + tail, dtype=dtype, device=_dev(views))
     if frames is not None:
-        shape[0] = frames.dim() - 1
-        shape[1:frames.dim()] = torch.tensor(frames.shape[1:], dtype=torch.int64)
-    dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)
-    tail = tuple(int(x) for x in shape[1:1 + int(shape[0])])
-    ref = frames if frames is not None else torch.zeros((0,) + tail, device=_dev(views))
-    send = torch.zeros((max_b,) + tail, dtype=ref.dtype, device=ref.device)
-    send[:hi - lo] = ref
+        send[:hi - lo] = frames
+    ref = send
     out = torch.empty((world * max_b,) + tail, dtype=ref.dtype, device=ref.device)
     dist.all_gather_into_tensor(out, send, group=group)
     out = out.reshape((world, max_b) + tail)
@@ -72,6 +94,10 @@ class OverlappedFrameGather:
         self.latest = None         # buffer of the most recently completed gather
 
     def submit(self, frames):
+        """Start the all-gather of `frames` [b, ...] and return the buffer of the most recently COMPLETED gather (None
+        until one has completed).  The returned tensor is one of the `depth` internal buffers: it is overwritten by the
+        gather issued `depth - 1` submits later — consume or clone it before that.  `frames` itself must stay untouched
+        until its gather has been retired (alternate `depth` frame buffers, as RNRPipeline does)."""
         buf = self.buffers[self.submitted % self.depth]
         work = dist.all_gather_into_tensor(buf, frames, group=self.group, async_op=True)
         self.pending.append((work, buf))

@@ -14,7 +14,69 @@ from ._lib import (RnrConvDesc, RnrConvSrc, RnrGbuffer, RnrMesh, RnrRays, check)
 
 
 def _stream():
+    """The current HIP stream of the CURRENT device.  Operators run inside `on_device(...)`, which makes the device of
+    their tensor arguments current first — the C side never calls hipSetDevice, and a kernel launched into another
+    device's stream faults (the reference pins everything to device 0, rasterize.py:50-69; we do not)."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda_tensors(x, depth=0):
+    if isinstance(x, torch.Tensor):
+        if x.is_cuda:
+            yield x
+    elif isinstance(x, DeviceMesh):
+        yield x.v
+    elif depth < 2 and isinstance(x, dict):
+        for v in x.values():
+            yield from _cuda_tensors(v, depth + 1)
+    elif depth < 2 and isinstance(x, (list, tuple)):
+        for v in x:
+            yield from _cuda_tensors(v, depth + 1)
+
+
+class on_device:
+    """Context: make `device` the current HIP device (no-op when it already is)."""
+
+    def __init__(self, device):
+        device = torch.device(device) if device is not None else None
+        idx = None if device is None else (device.index if device.index is not None else torch.cuda.current_device())
+        self._ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*exc)
+        return False
+
+
+def _device_op(fn):
+    """Run `fn` with the device of its tensor arguments current; raise if the arguments span devices."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for a in args:
+            for t in _cuda_tensors(a):
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise RuntimeError('%s: arguments live on different devices (%s and %s)' % (fn.__name__, dev, t.device))
+        for a in kwargs.values():
+            for t in _cuda_tensors(a):
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise RuntimeError('%s: arguments live on different devices (%s and %s)' % (fn.__name__, dev, t.device))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -36,6 +98,7 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------------------
 # neural_renderer.cuda.rasterize drop-ins
 # ---------------------------------------------------------------------------------------------------
+@_device_op
 def forward_face_index_map(faces, face_index_map, weight_map, depth_map, face_inv_map, faces_inv, image_size, near,
                            far, return_rgb, return_alpha, return_depth):
     """rasterize_cuda.cpp:66-98.  In-place on the caller's pre-filled buffers; returns them."""
@@ -53,6 +116,7 @@ def forward_face_index_map(faces, face_index_map, weight_map, depth_map, face_in
     return [face_index_map, weight_map, depth_map, face_inv_map]
 
 
+@_device_op
 def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_map, rgb_map, sampling_index_map,
                              sampling_weight_map, image_size, eps):
     """rasterize_cuda.cpp:100-122."""
@@ -68,6 +132,7 @@ def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_
     return [rgb_map, sampling_index_map, sampling_weight_map]
 
 
+@_device_op
 def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, image_size,
                        eps, return_rgb, return_alpha):
     """rasterize_cuda.cpp:124-147.  grad_faces [B,nf,3,3] (pre-filled 0) is written in place and returned; the maps a
@@ -87,6 +152,7 @@ def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, 
     return grad_faces
 
 
+@_device_op
 def backward_textures(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, num_faces):
     """rasterize_cuda.cpp:149-165.  grad_textures [B,nf,ts,ts,ts,3] (pre-filled 0) accumulated in place."""
     L = _lib.load()
@@ -100,6 +166,7 @@ def backward_textures(face_index_map, sampling_weight_map, sampling_index_map, g
     return grad_textures
 
 
+@_device_op
 def backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
                        image_size):
     """rasterize_cuda.cpp:167-189.  Adds the depth-map gradient to grad_faces in place."""
@@ -114,6 +181,7 @@ def backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_ma
     return grad_faces
 
 
+@_device_op
 def load_textures(image, faces, textures, is_update, texture_wrapping, use_bilinear):
     """load_textures_cuda.cpp:20-34.  `faces` [nf,3,2] uv are wrapped in place, `textures` [nf,ts,ts,ts,3] updated in
     place for the faces flagged in is_update [nf] int32; returns textures."""
@@ -125,6 +193,7 @@ def load_textures(image, faces, textures, is_update, texture_wrapping, use_bilin
     return textures
 
 
+@_device_op
 def create_texture_image(vertices_all, textures, image, eps):
     """create_texture_image_cuda.cpp:17-29.  Fills `image` [H,W,3] in place and returns it."""
     L = _lib.load()
@@ -137,6 +206,7 @@ def create_texture_image(vertices_all, textures, image, eps):
 # ---------------------------------------------------------------------------------------------------
 # fused path
 # ---------------------------------------------------------------------------------------------------
+@_device_op
 def project_vertices(vertices, K, R, t, orig_size, dist_coeffs=None, offset=None, scale=None, eps=1e-9):
     """nr.projection for a shared mesh: vertices [nv,3], K/R [N,3,3], t [N,3] -> [N,nv,3]."""
     L = _lib.load()
@@ -170,7 +240,8 @@ class DeviceMesh:
         if self._tangents is None:
             L = _lib.load()
             out = torch.empty(self.num_faces, 3, dtype=torch.float32, device=self.v.device)
-            check(L.rnr_face_tangents(ctypes.byref(self.c), _ptr(out), _stream()))
+            with on_device(self.v.device):
+                check(L.rnr_face_tangents(ctypes.byref(self.c), _ptr(out), _stream()))
             self._tangents = out
         return self._tangents
 
@@ -182,6 +253,7 @@ GBUFFER_MAPS = {'face_index_map': (torch.int32, ()), 'alpha': (torch.float32, ()
                 'position_map_cam': (torch.float32, (3,))}
 
 
+@_device_op
 def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=None, out=None, workspace=None):
     """network.Rasterizer.forward's per-pixel maps in one pass.  Returns dict name -> tensor [N,S,S(,k)]."""
     L = _lib.load()
@@ -203,6 +275,7 @@ def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=Non
     return out
 
 
+@_device_op
 def shade_inputs(gb, mesh, proj_inv, R_inv, textures, pivots_spec, pivots_diff, sh_start_ch, c_pad=None,
                  want_rays_uv=False, want_neural_img=False, want_sh=False, net_in=None):
     """G-buffer -> channel-last RenderingNet input [N,H,W,c_pad] (+ optional API copies).
@@ -235,6 +308,7 @@ def shade_inputs(gb, mesh, proj_inv, R_inv, textures, pivots_spec, pivots_diff, 
     return {'net_in': net_in, 'rays_uv': rays_uv, 'neural_img': neural, 'sh_basis_map': sh, 'c_pad': c_pad}
 
 
+@_device_op
 def ray_render(unet_raw, bias, net_in, alpha, lp, num_spec, num_diff, albedo_diff_ch=0, albedo_spec_ch=3, image=None):
     """bias+tanh + rays_lt scaling + RayRenderer.forward (seperate_albedo=True) -> [N,3,H,W]."""
     L = _lib.load()
@@ -249,6 +323,7 @@ def ray_render(unet_raw, bias, net_in, alpha, lp, num_spec, num_diff, albedo_dif
     return image
 
 
+@_device_op
 def sh_basis(dirs, lmax):
     """sph_harm.evaluate_sh_basis: dirs [n,3] -> [n,(lmax+1)^2] float32."""
     L = _lib.load()
@@ -258,6 +333,7 @@ def sh_basis(dirs, lmax):
     return out
 
 
+@_device_op
 def sh_reconstruct(basis, coeff):
     """sph_harm.reconstruct_sh for coeff [nb,C]: -> [ns,C]."""
     L = _lib.load()
@@ -268,6 +344,7 @@ def sh_reconstruct(basis, coeff):
     return out
 
 
+@_device_op
 def sh_fit(samples, basis):
     """sph_harm.fit_sh_coeff for samples [ns,C]: -> [nb,C]."""
     L = _lib.load()
@@ -278,6 +355,7 @@ def sh_fit(samples, basis):
     return out
 
 
+@_device_op
 def interpolate_bilinear(data, x, y, want_taps=False):
     """misc.interpolate_bilinear: data [H,W,C], x/y [...] -> [...,C] (+ int32 taps [...,4])."""
     L = _lib.load()
@@ -294,6 +372,7 @@ def interpolate_bilinear(data, x, y, want_taps=False):
     return (out, taps.reshape(*shp, 4)) if want_taps else out
 
 
+@_device_op
 def nchw_to_nhwc(x, c_pad):
     L = _lib.load()
     _chk(x, 'x')
@@ -303,6 +382,7 @@ def nchw_to_nhwc(x, c_pad):
     return out
 
 
+@_device_op
 def nhwc_to_nchw(x, c, bias=None, apply_tanh=False):
     L = _lib.load()
     _chk(x, 'x')
@@ -315,6 +395,7 @@ def nhwc_to_nchw(x, c, bias=None, apply_tanh=False):
 # ---------------------------------------------------------------------------------------------------
 # stand-alone operators behind the drop-in Python API
 # ---------------------------------------------------------------------------------------------------
+@_device_op
 def view_dir_map(img_hw, proj_inv, R_inv):
     """camera.get_view_dir_map -> (world [N,H,W,3], cam [N,H,W,3])."""
     L = _lib.load()
@@ -326,6 +407,7 @@ def view_dir_map(img_hw, proj_inv, R_inv):
     return world, cam
 
 
+@_device_op
 def face_tangents(faces_v, faces_vt):
     """Per-face unit tangents from gathered per-face positions [nf,3,3] and texcoords [nf,3,2] (render.py:135-150)."""
     L = _lib.load()
@@ -340,6 +422,7 @@ def face_tangents(faces_v, faces_vt):
     return out
 
 
+@_device_op
 def tbn_map(normal_map, face_index_map, tangents):
     """render.get_TBN_map body given unit per-face tangents -> [N,H,W,3,3]."""
     L = _lib.load()
@@ -351,6 +434,7 @@ def tbn_map(normal_map, face_index_map, tangents):
     return out
 
 
+@_device_op
 def ray_sampler(reflect, pivots, tbn, view_tangent, alpha):
     """network.RaySampler.forward.  tbn [...,3,3], view_tangent [...,3], alpha [...,1] -> dirs [...,3,R], uv [...,2,R],
     dirs_tangent [...,3,R] (reflect) or the pivots (diffuse)."""
@@ -373,6 +457,7 @@ def ray_sampler(reflect, pivots, tbn, view_tangent, alpha):
     return dirs, uv, dt
 
 
+@_device_op
 def texture_mapper(textures, uv_map, sh_basis_map=None, sh_start_ch=3):
     """network.TextureMapper.forward for any channel count -> [N,C,H,W]."""
     L = _lib.load()
@@ -391,6 +476,7 @@ def texture_mapper(textures, uv_map, sh_basis_map=None, sh_start_ch=3):
     return out
 
 
+@_device_op
 def ray_renderer(rays_uv, rays_lt, lp, albedo_specular, albedo_diffuse=None, num_ray_diffuse=0, no_albedo=False,
                  seperate_albedo=False, lp_scale_factor=1.0):
     """network.RayRenderer.forward on API-shaped tensors -> (out, out_spec, out_diff, ltt_spec, ltt_diff, rays_color)."""

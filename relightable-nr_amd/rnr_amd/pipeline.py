@@ -96,6 +96,10 @@ class RNRPipeline:
         two internal buffers used alternately: it stays valid until the call after next.
         stage_events: optional list; (name, torch.cuda.Event) pairs are appended at the stage boundaries
         (measurement only — bench.py's per-stage HBM figures)."""
+        with ops.on_device(self.dev):
+            return self._render(proj, pose, proj_inv, R_inv, keep_intermediates, lighting_idx, stage_events)
+
+    def _render(self, proj, pose, proj_inv, R_inv, keep_intermediates, lighting_idx, stage_events):
 
         def mark(name):
             if stage_events is not None:

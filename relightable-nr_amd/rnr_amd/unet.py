@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import (ACT_LRELU02, ACT_NONE, ACT_RELU, CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2, RnrConvDesc,
                    RnrConvSrc, check)
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, on_device
 
 
 def _pad16(c):
@@ -33,8 +33,14 @@ class _Act:
 
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
-                 prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None, precision='f32'):
-        """bn_mode 'batch': BatchNorm2d in train mode (per-view batch statistics, what test_rnr.py:229-233 forces);
+                 prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None, precision='f32',
+                 update_running_stats=False):
+        """bn_mode 'batch': BatchNorm2d in train mode with PER-VIEW batch statistics — what test_rnr.py:229-233 forces,
+        evaluated the way the reference evaluates it (one view per call); a batch of N poses is N independent frames.
+        'batch_all': train-mode BatchNorm2d exactly as torch computes it for ONE call with an [N,C,H,W] input: statistics
+        over the whole batch (N,H,W), identical for every view (what the drop-in `Unet.forward` must return for N > 1);
+        with update_running_stats the running_mean / running_var tensors of the state-dict are updated in place
+        (momentum 0.1, unbiased variance) like torch does.
         'running': eval-mode BatchNorm from the running_mean / running_var buffers of the state-dict.
         precision 'f32': exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  'bf16x6': fp32 emulated on the bf16 matrix cores —
         operands split exactly into three bf16 terms, six partial products accumulated in fp32; error of the order of
@@ -43,6 +49,9 @@ class UNetPlan:
         (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
         if precision not in ('f32', 'bf16x6'):
             raise ValueError("precision must be 'f32' or 'bf16x6'")
+        if bn_mode not in ('batch', 'batch_all', 'running'):
+            raise ValueError("bn_mode must be 'batch', 'batch_all' or 'running'")
+        self.bn_mode = bn_mode
         self.precision = precision
         self.L = _lib.load()
         self.dev = device
@@ -71,7 +80,8 @@ class UNetPlan:
             else:
                 w = g(wkey)
                 packed = torch.empty(self.L.rnr_packed_weight_floats(ctypes.byref(desc)), dtype=torch.float32, device=device)
-                check(self.L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(w), _ptr(packed), _stream()))
+                with on_device(device):
+                    check(self.L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(w), _ptr(packed), _stream()))
             if kind == CONV3x3_REFLECT:
                 oh, ow = s0.h, s0.w
             elif kind == CONV4x4S2_REFLECT:
@@ -93,8 +103,14 @@ class UNetPlan:
                 out.shift = torch.empty(self.N, desc.c_out_pad, dtype=torch.float32, device=device)
                 # statistics start at zero and every rnr_bn_finalize_reset leaves them at zero: no memset per layer
                 desc.flags |= _lib.CONV_STATS_PREZEROED
-                step['bn'] = {'gamma': gamma, 'beta': beta,
+                step['bn'] = {'gamma': gamma, 'beta': beta, 'running_mean': None, 'running_var': None,
                               'stats': torch.zeros(self.N, desc.c_out_pad, 2, dtype=torch.float64, device=device)}
+                if bn_mode == 'batch_all' and update_running_stats and has(bn_key + '.running_mean'):
+                    rm, rv = sd[prefix + bn_key + '.running_mean'], sd[prefix + bn_key + '.running_var']
+                    if not (rm.is_cuda and rm.dtype == torch.float32 and rm.is_contiguous() and
+                            rv.is_cuda and rv.dtype == torch.float32 and rv.is_contiguous()):
+                        raise RuntimeError('update_running_stats needs float32 device-resident running buffers')
+                    step['bn']['running_mean'], step['bn']['running_var'] = rm, rv      # updated IN PLACE
             elif bias_key is not None and has(bias_key):
                 b = torch.zeros(desc.c_out_pad, dtype=torch.float32, device=device)
                 b[:c_out] = g(bias_key)
@@ -160,7 +176,13 @@ class UNetPlan:
         """net_in [n,H,W,in_c_pad] channel-last -> raw out-layer output [n,H,W,out_c_pad] (bias/tanh NOT applied).
         consumer_alpha [n,H,W]: promise that the caller reads the result only where alpha > 0 (the ray renderer zeroes
         background pixels); the out layer then skips pixel tiles without any such pixel and leaves them unwritten."""
+        with on_device(self.dev):
+            return self._forward(net_in, n_views, consumer_alpha)
+
+    def _forward(self, net_in, n_views, consumer_alpha):
         n = net_in.shape[0] if n_views is None else n_views
+        if net_in.device != torch.device(self.dev) and not (net_in.is_cuda and torch.device(self.dev).index is None):
+            raise RuntimeError('net_in lives on %s, the plan on %s' % (net_in.device, self.dev))
         if n > self.N:
             raise RuntimeError('UNetPlan built for at most %d views, got %d' % (self.N, n))
         if net_in.shape[-1] != self.in_c_pad or net_in.shape[1] != self.H or net_in.shape[2] != self.W:
@@ -198,7 +220,11 @@ class UNetPlan:
             check(L.rnr_conv2d_masked(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
                                       _ptr(s['packed']), _ptr(out.data), _ptr(bn['stats']) if bn else None, n, h, w,
                                       _ptr(self.workspace), self.ws_bytes, _ptr(mask) if s is last else None, st))
-            if bn:
+            if bn and self.bn_mode == 'batch_all':
+                check(L.rnr_bn_finalize_batch(_ptr(bn['stats']), _ptr(bn['gamma']), _ptr(bn['beta']), _ptr(out.scale),
+                                              _ptr(out.shift), _ptr(bn['running_mean']), _ptr(bn['running_var']), 0.1, n,
+                                              out.c, out.c_pad, float(out.h * out.w), 1e-5, st))
+            elif bn:
                 check(L.rnr_bn_finalize_reset(_ptr(bn['stats']), _ptr(bn['gamma']), _ptr(bn['beta']), _ptr(out.scale),
                                         _ptr(out.shift), n, out.c, out.c_pad, float(out.h * out.w), 1e-5, st))
         return self.out.data[:n]

@@ -33,6 +33,13 @@ def _worker(rank, world, port, B, q):
         lo, hi = rdist.shard_bounds(B, world, rank)
         local = rdist.render_views_sharded(_fake_render, views, gather=False)
         ok = ok and ((local is None and hi == lo) or torch.equal(local, ref[lo:hi]))
+        # non-float32 frames with an empty shard on one rank: the dtype must be agreed, not assumed (uint8 frames)
+        as_u8 = lambda v: (_fake_render(v).abs() * 10).clamp(max=255).to(torch.uint8)
+        out8 = rdist.render_views_sharded(as_u8, views)
+        ok = ok and out8.dtype == torch.uint8 and torch.equal(out8, as_u8(views))
+        # caller-stated shape / dtype: no agreement round
+        outh = rdist.render_views_sharded(lambda v: _fake_render(v).half(), views, frame_shape=(3, 4, 4), frame_dtype=torch.float16)
+        ok = ok and outh.dtype == torch.float16 and torch.equal(outh, ref.half())
         q.put((rank, bool(ok), (lo, hi)))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,45 @@
+"""-m gpu: the multi-GPU launch path on the one GPU this suite gets: `python -m torch.distributed.run --nproc-per-node 1
+bench.py` with the RCCL path forced on (backend "nccl" = RCCL).  What is checked: process-group start-up on the GPU,
+the asynchronous double-buffered `all_gather_into_tensor` of frames (rnr_amd.dist.OverlappedFrameGather) delivering
+bit-identical frames, the bench JSON contract under the launcher.  Scaling numbers are the driver's to measure."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert lines, p.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_under_torchrun_rccl_gather():
+    env = dict(os.environ, RNR_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29600 + os.getpid() % 300
+    res = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1',
+                '--views-per-step', '2', '--no-cpu-baseline', '--main-loop-only', '--check-gather'], env)
+    assert res['n_gpus'] == 1 and res['steps'] == 2 and res['warmup'] == 1
+    assert res['gather_check']['ok'] is True, res['gather_check']
+    assert res['gather_check']['backend'] == 'nccl'
+    assert res['gather_check']['gathered_shape'] == [2, 3, 512, 512]
+    assert res['value'] > 10.0 and res['scaling'] == 'weak'
+    assert res['roofline']['frac'] > 0.1 and res['cpu_baseline'] is None
+
+
+def test_bench_plain_launch_forced_dist():
+    """Same path without the launcher (RANK/WORLD_SIZE absent): bench.py must default to a 1-rank group on 127.0.0.1."""
+    env = dict(os.environ, RNR_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_PORT=str(29900 + os.getpid() % 90))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    res = _run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--views-per-step', '1', '--no-cpu-baseline',
+                '--main-loop-only', '--check-gather'], env)
+    assert res['gather_check']['ok'] is True

@@ -55,6 +55,72 @@ def test_frame256_vs_oracle():
     assert p > 55.0, p
 
 
+def _bench_scene():
+    """The BASELINE configs[2] workload exactly as bench.py builds it: UV-sphere 128 x 256 (65 536 faces), neural texture
+    512^2 x 24 ch x 4 levels, RenderingNet 108 -> 78 with nf0 = 64, SH lighting lmax 10, 512^2."""
+    from rnr_amd import scene, testing
+    ps, pd = testing.ray_pivots(6, 2, 5), testing.ray_pivots(6, 2, 10)
+    return {'mesh': scene.uv_sphere(128, 256), 'textures': testing.synthetic_textures(512, 24, 4, 0),
+            'unet_sd': testing.unet_state_dict(108, 78, 64, 5, 0), 'pivots_spec': ps, 'pivots_diff': pd,
+            'sh_coeff': torch.from_numpy(scene.synthetic_sh_coeff(2, 10, 1))}
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16x6'])
+def test_frame512_nf64_vs_oracle(precision):
+    """Parity AT THE BENCHMARKED SIZE (test_rnr.py:265-377): 65 536 faces, C = 24, nf0 = 64, 512^2.
+      * face_index_map / alpha EQUAL to the oracle on the same projected vertices (bit-exact integer bar);
+      * network input <= 2e-5 abs vs the oracle's test_rnr.py:303-356 assembly;
+      * U-Net output (tanh) <= 5e-4 abs vs orc.unet_forward on the same input; frame PSNR >= 60 dB;
+      * a batch of 8 poses == 8 batches of 1 pose to 1e-5 (BatchNorm statistics are per view at the bench's batch)."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    from rnr_amd.pipeline import RNRPipeline
+    S = 512
+    sc = _bench_scene()
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=64,
+                       max_views=8, device=DEV, sh_coeff=sc['sh_coeff'], sh_lmax=10, skip_background_tiles=False,
+                       precision=precision)
+    ids = [37, 400, 5, 123, 250, 333, 600, 719]
+    views = {k: T(v) for k, v in scene.spiral_views(S, ids).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    r = lambda sl: pipe.render(dv['proj'][sl], dv['pose'][sl], dv['proj_inv'][sl], dv['R_inv'][sl])
+    img2 = r(slice(0, 2)).clone()
+    pipe.render(dv['proj'][:2], dv['pose'][:2], dv['proj_inv'][:2], dv['R_inv'][:2], keep_intermediates=True)
+    last = pipe.last
+    v_uvz = last['v_uvz'].cpu()
+    # ---- oracle on the same projected vertices, two views
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    v2 = {k: v[:2] for k, v in views.items()}
+    gb = orc.rasterizer_forward(mesh_t, v2['proj'], v2['pose'], S, v_uvz_ndc=v_uvz)
+    assert torch.equal(last['gb']['face_index_map'].cpu(), gb['face_index_map'])
+    assert torch.equal(last['gb']['alpha'].cpu(), gb['alpha'])
+    sh_in = orc.shade_inputs(gb, v2['proj_inv'], v2['R_inv'], sc['textures'], sc['pivots_spec'], sc['pivots_diff'], 6)
+    net_in = last['net_in'][..., :108].permute(0, 3, 1, 2).cpu()
+    d = (net_in - sh_in['net_in']).abs()
+    assert d.max() <= 2e-5, d.max()
+    assert float(last['net_in'][..., 108:].abs().max()) == 0.0          # pad channels
+    # ---- U-Net on the SAME input (isolates the 22 convolutions + batch-stat BN at full width)
+    y_ref = orc.unet_forward(sc['unet_sd'], net_in)
+    from rnr_amd import ops
+    y = ops.nhwc_to_nchw(last['unet_raw'], 78, bias=pipe.unet.out_bias, apply_tanh=True).cpu()
+    assert (y - y_ref).abs().max() <= 5e-4, (y - y_ref).abs().max()
+    # ---- frame
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]
+    rays_lt = (y_ref.reshape(2, 26, -1, S, S) * 0.5 + 0.5) * 2.0
+    neural = sh_in['neural_img']
+    ref_img = orc.ray_renderer(neural[:, 3:6], sh_in['rays_uv'], rays_lt, lp, albedo_diffuse=neural[:, :3],
+                               num_ray_diffuse=13, seperate_albedo=True)[0]
+    p = orc.psnr(img2.cpu(), ref_img)
+    assert p >= 60.0, p
+    # ---- batch of 8 == 8 x batch of 1
+    img8 = r(slice(0, 8)).clone()
+    assert (img8[:2] - img2).abs().max() <= 1e-5
+    for i in range(8):
+        one = r(slice(i, i + 1))
+        assert (one - img8[i:i + 1]).abs().max() <= 1e-5, i
+
+
 def test_frame1024_c16_vs_oracle():
     """BASELINE config 5 shape class: 1024x1024, 16-channel neural texture (U-Net input 78 + 6 + 16 = 100 -> 78),
     lighting from a 4096-sample SH projection of an environment map (lmax 10).  Small nf0 keeps the CPU oracle fast."""
