@@ -339,6 +339,12 @@ int rnr_sh_fit(const float* samples, const float* basis, float* out, int num_sam
 int rnr_interpolate_bilinear(const float* data, int h, int w, int c, const float* x, const float* y,
                              float* out, int32_t* taps, int n, void* stream);
 
+/* Area-average resize of a channel-last image src [src_h,src_w,C] -> dst [dst_h,dst_w,C]: the
+ * cv2.resize(..., interpolation=cv2.INTER_AREA) call of LightingLP.__init__ (network.py:667) restated from OpenCV's
+ * published algorithm (fractional-coverage box filter when shrinking on both axes, "area-mode" bilinear otherwise).
+ * cv2 is not available in this image: parity with OpenCV is unpinned; the integer-ratio case is the plain box mean. */
+int rnr_resize_area(const float* src, float* dst, int src_h, int src_w, int dst_h, int dst_w, int channels, void* stream);
+
 /* =====================================================================================================
  * 3. Stand-alone operators for the drop-in Python API (one reference function each).  The fused entry
  *    points above compute the same quantities without the intermediate HBM round trips.
@@ -374,6 +380,21 @@ int rnr_ray_renderer(const float* rays_uv, const float* rays_lt, const float* lp
                      float lp_scale_factor, float* out, float* out_specular, float* out_diffuse,
                      float* ltt_specular, float* ltt_diffuse, float* rays_color, int num_views, int height,
                      int width, void* stream);
+
+/* =====================================================================================================
+ * 4. Host-side data front-end: Wavefront OBJ reader behind nr.load_obj(normalization=False, load_texture=False)
+ *    (neural_renderer/load_obj.py:108-209: four Python passes over the lines).  No GPU involved.
+ *    Two calls: rnr_obj_scan counts the elements, the caller allocates, rnr_obj_parse fills:
+ *    v [nv,3], vn [nvn,3], vt [nvt,2] float32 (correctly rounded double -> float32, like float() + astype(float32));
+ *    f_v_idx / f_vt_idx / f_vn_idx [nf,3] int32, 0-based.  vt / vn index arrays are filled iff the file holds vt / vn
+ *    lines (the reference's has_vt / has_vn, load_obj.py:133-176).  Triangles only; errors via rnr_last_error.
+ * ===================================================================================================== */
+typedef struct rnr_obj_counts {
+    long num_vertices, num_normals, num_texcoords, num_faces;
+} rnr_obj_counts;
+int rnr_obj_scan(const char* text, size_t len, rnr_obj_counts* counts);
+int rnr_obj_parse(const char* text, size_t len, const rnr_obj_counts* counts, float* v, float* vn, float* vt,
+                  int32_t* f_v_idx, int32_t* f_vt_idx, int32_t* f_vn_idx);
 
 #ifdef __cplusplus
 }

@@ -348,6 +348,59 @@ def reconstruct_lp(coeff, basis_recon, h=100, w=200):
     return reconstruct_sh(coeff, basis_recon).reshape(h, w, -1)
 
 
+def _area_tab(ssize, dsize):
+    """OpenCV computeResizeAreaTab (imgproc/resize.cpp): list of (dst index, src index, weight) for one axis when
+    shrinking (scale = ssize/dsize >= 1)."""
+    scale = ssize / dsize
+    tab = []
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1 = int(math.ceil(f1))
+        s2 = min(int(math.floor(f2)), ssize - 1)
+        s1 = min(s1, s2)
+        if s1 - f1 > 1e-3:
+            tab.append((d, s1 - 1, np.float32((s1 - f1) / cell)))
+        for sx in range(s1, s2):
+            tab.append((d, sx, np.float32(1.0 / cell)))
+        if f2 - s2 > 1e-3:
+            tab.append((d, s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+    return tab
+
+
+def resize_area(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_AREA) as LightingLP.__init__ calls it (network.py:667),
+    restated from OpenCV's published algorithm — cv2 is absent here, so this restatement is PARITY-UNPINNED against
+    OpenCV itself; tests pin its integer-ratio case against the plain box mean.  img [H,W,C] float32 numpy."""
+    img = np.asarray(img, np.float32)
+    H, W, C = img.shape
+    if W >= out_w and H >= out_h:
+        def mat(ssize, dsize):
+            m = np.zeros((dsize, ssize), np.float32)
+            for d, s_, a in _area_tab(ssize, dsize):
+                m[d, s_] += a
+            return m
+        mx, my = mat(W, out_w), mat(H, out_h)
+        tmp = np.einsum('dx,yxc->ydc', mx, img).astype(np.float32)          # rows first, like the kernel
+        return np.einsum('ey,ydc->edc', my, tmp).astype(np.float32)
+
+    def lin(ssize, dsize):
+        scale = ssize / dsize
+        d = np.arange(dsize)
+        s0 = np.floor(d * scale).astype(np.int64)
+        f = ((d + 1) - (s0 + 1) / scale).astype(np.float32)
+        f = np.where(f <= 0, np.float32(0), f - np.floor(f)).astype(np.float32)
+        s0 = np.minimum(s0, ssize - 1)
+        return s0, np.minimum(s0 + 1, ssize - 1), f
+    x0, x1, fx = lin(W, out_w)
+    y0, y1, fy = lin(H, out_h)
+    fx, fy = fx[None, :, None], fy[:, None, None]
+    top = img[y0][:, x0] * (1 - fx) + img[y0][:, x1] * fx
+    bot = img[y1][:, x0] * (1 - fx) + img[y1][:, x1] * fx
+    return (top * (1 - fy) + bot * fy).astype(np.float32)
+
+
 # ------------------------------------------------------------------------------------------------
 # U-Net (RenderingNet)
 # ------------------------------------------------------------------------------------------------

@@ -901,6 +901,78 @@ extern "C" int rnr_interpolate_bilinear(const float* data, int h, int w, int c, 
     return check_launch("interpolate_bilinear_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Area-average image resize: what LightingLP.__init__ asks of cv2.resize(..., interpolation=cv2.INTER_AREA)
+// (network.py:667) for the 1600 x 3200 light probes.  Restated from OpenCV's published algorithm (imgproc/resize.cpp):
+//   * shrinking on both axes (scale = src/dst >= 1): separable box filter with fractional cell coverage
+//     (computeResizeAreaTab): cell [d*scale, (d+1)*scale) of the source axis; a partially covered first pixel weighs
+//     (ceil(f1) - f1), whole pixels 1, a partially covered last pixel min(f2 - floor(f2), 1), all divided by
+//     cellWidth = min(scale, ssize - f1); partial coverage below 1e-3 is dropped.  Integer ratios reduce to the plain
+//     box mean.
+//   * otherwise (enlarging on an axis): OpenCV switches to its "area-mode" bilinear: s = floor(d*scale),
+//     f = (d+1) - (s+1)/scale, f <= 0 ? 0 : f - floor(f); out = (1-f)*src[s] + f*src[min(s+1, ssize-1)].
+// cv2 is absent from this image: parity with OpenCV is UNPINNED (the oracle pins the integer-ratio case against a
+// numpy box mean).  One lane per (output pixel, channel); an init-time operator, not on the per-view path.
+__device__ __forceinline__ void area_cell(int d, double scale, int ssize, int& s1, int& s2, float& a_first, float& a_mid,
+                                          float& a_last) {
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, (double)ssize - f1);
+    s1 = (int)ceil(f1);
+    s2 = (int)floor(f2);
+    s2 = min(s2, ssize - 1);
+    s1 = min(s1, s2);
+    a_first = (s1 - f1 > 1e-3) ? (float)((s1 - f1) / cell) : 0.0f;          // weight of pixel s1 - 1
+    a_mid = (float)(1.0 / cell);                                            // pixels s1 .. s2 - 1
+    a_last = (f2 - s2 > 1e-3) ? (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell) : 0.0f;   // weight of pixel s2
+}
+
+__global__ void __launch_bounds__(256)
+resize_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int sh, int sw, int dh, int dw, int c) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)dh * dw * c) return;
+    const int ch = (int)(i % c);
+    const int dx = (int)((i / c) % dw), dy = (int)(i / ((long)c * dw));
+    const double scx = (double)sw / dw, scy = (double)sh / dh;
+    float acc = 0.0f;
+    if (scx >= 1.0 && scy >= 1.0) {
+        int x1, x2, y1, y2;
+        float xa, xm, xl, ya, ym, yl;
+        area_cell(dx, scx, sw, x1, x2, xa, xm, xl);
+        area_cell(dy, scy, sh, y1, y2, ya, ym, yl);
+        for (int y = y1 - 1; y <= y2; y++) {
+            const float wy = y < y1 ? ya : (y < y2 ? ym : yl);
+            if (wy == 0.0f || y < 0) continue;
+            float row = 0.0f;
+            for (int x = x1 - 1; x <= x2; x++) {
+                const float wx = x < x1 ? xa : (x < x2 ? xm : xl);
+                if (wx == 0.0f || x < 0) continue;
+                row += src[((size_t)y * sw + x) * c + ch] * wx;
+            }
+            acc += row * wy;
+        }
+    } else {
+        int sx = (int)floor(dx * scx), sy = (int)floor(dy * scy);
+        float fx = (float)((dx + 1) - (sx + 1) / scx), fy = (float)((dy + 1) - (sy + 1) / scy);
+        fx = fx <= 0.0f ? 0.0f : fx - floorf(fx);
+        fy = fy <= 0.0f ? 0.0f : fy - floorf(fy);
+        sx = min(sx, sw - 1); sy = min(sy, sh - 1);
+        const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+        const float v00 = src[((size_t)sy * sw + sx) * c + ch], v01 = src[((size_t)sy * sw + sx1) * c + ch];
+        const float v10 = src[((size_t)sy1 * sw + sx) * c + ch], v11 = src[((size_t)sy1 * sw + sx1) * c + ch];
+        acc = (v00 * (1.0f - fx) + v01 * fx) * (1.0f - fy) + (v10 * (1.0f - fx) + v11 * fx) * fy;
+    }
+    dst[i] = acc;
+}
+
+extern "C" int rnr_resize_area(const float* src, float* dst, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                               void* stream) {
+    RNR_REQUIRE(src && dst && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && channels > 0, "rnr_resize_area: bad arguments");
+    const long total = (long)dst_h * dst_w * channels;
+    hipLaunchKernelGGL(resize_area_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst,
+                       src_h, src_w, dst_h, dst_w, channels);
+    return check_launch("resize_area_kernel");
+}
+
 extern "C" int rnr_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream) {
     RNR_REQUIRE(in && out && n > 0 && c > 0 && c_pad >= c, "rnr_nchw_to_nhwc: bad arguments");
     const long total = (long)n * h * w * c_pad;

@@ -1,7 +1,7 @@
 """Drop-in `dataio.ViewDataset` for inference (reference: dataio.py:11-247): calib.mat -> per-view camera tensors.
 
-Only what `test_rnr.py:112-119, 268-278` needs: `load_img=False`, `load_precompute=False`.  Image loading, the
-precomputed-map loader and `LightProbeDataset` (cv2) are outside the hot-path build and raise.
+Only what `test_rnr.py:112-127, 268-278` needs: `load_img=False`, `load_precompute=False` (image loading and the
+precomputed-map loader are outside the hot-path build and raise) and a cv2-free `LightProbeDataset`.
 
 Unlike the reference, `read_view` is pure: the reference writes the cropped intrinsics back into `calib['projs']`
 through a numpy view (dataio.py:189-193), so calling it twice for the same index compounds the crop.  The values
@@ -100,6 +100,77 @@ class ViewDataset():
         return [view]
 
 
+def _read_radiance_hdr(fp):
+    """Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y H +X W orientation) -> float32 [H,W,3] RGB."""
+    with open(fp, 'rb') as fh:
+        data = fh.read()
+    pos = data.index(b'\n\n') + 2
+    end = data.index(b'\n', pos)
+    dims = data[pos:end].split()
+    if len(dims) != 4 or dims[0] != b'-Y' or dims[2] != b'+X':
+        raise ValueError('%s: unsupported Radiance orientation %r' % (fp, data[pos:end]))
+    H, W = int(dims[1]), int(dims[3])
+    buf = np.frombuffer(data, np.uint8, offset=end + 1)
+    rgbe = np.empty((H, W, 4), np.uint8)
+    p = 0
+    for y in range(H):
+        if W < 8 or W > 0x7fff or buf[p] != 2 or buf[p + 1] != 2 or (buf[p + 2] & 0x80):
+            rgbe[y] = buf[p:p + 4 * W].reshape(W, 4)           # flat scanline
+            p += 4 * W
+            continue
+        p += 4
+        for ch in range(4):
+            x = 0
+            while x < W:
+                n = int(buf[p]); p += 1
+                if n > 128:                                     # run
+                    n -= 128
+                    rgbe[y, x:x + n, ch] = buf[p]; p += 1
+                else:                                           # literal
+                    rgbe[y, x:x + n, ch] = buf[p:p + n]; p += n
+                x += n
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(1.0, e - 136), 0.0).astype(np.float32)
+    return rgbe[..., :3].astype(np.float32) * scale[..., None]
+
+
 class LightProbeDataset():
-    def __init__(self, *a, **k):
-        raise NotImplementedError('LightProbeDataset reads HDR probes with cv2; outside the hot-path build (SURVEY §8(f))')
+    """dataio.py:262-311 without cv2: items are {'lp_img': float32 tensor [3,H,W], RGB, ** img_gamma}.  Readers: Radiance
+    `.hdr` (numpy RGBE decoder), `.npy` ([H,W,3] float RGB), 8-bit `.png/.jpg/.jpeg` via PIL (/255).  OpenEXR needs a
+    codec this image does not ship: convert such probes to .hdr or .npy."""
+    _EXT = ('.png', '.jpg', '.jpeg', '.JPG', '.JPEG', '.hdr', '.exr', '.npy')
+
+    def __init__(self, data_dir, img_gamma=1.0):
+        self.data_dir, self.img_gamma = data_dir, img_gamma
+        if not os.path.isdir(data_dir):
+            raise ValueError("Error! data dir is wrong")
+        self.lp_fp_all = sorted(os.path.join(data_dir, f) for f in os.listdir(data_dir) if f.endswith(self._EXT))
+        self.lp_all = [None] * len(self.lp_fp_all)
+
+    def buffer_one(self, idx):
+        if self.lp_all[idx] is not None:
+            return
+        fp = self.lp_fp_all[idx]
+        ext = os.path.splitext(fp)[1].lower()
+        if ext == '.hdr':
+            img = _read_radiance_hdr(fp)
+        elif ext == '.npy':
+            img = np.load(fp).astype(np.float32)[:, :, :3]
+        elif ext == '.exr':
+            raise NotImplementedError('%s: OpenEXR needs cv2 / OpenEXR, absent here - convert the probe to .hdr or .npy' % fp)
+        else:
+            from PIL import Image
+            img = np.asarray(Image.open(fp).convert('RGB'), np.float32) / 255.0
+        img = np.ascontiguousarray(img.transpose(2, 0, 1)) ** self.img_gamma
+        self.lp_all[idx] = {'lp_img': torch.from_numpy(img.astype(np.float32))}
+
+    def buffer_all(self):
+        for idx in range(len(self.lp_fp_all)):
+            self.buffer_one(idx)
+
+    def __len__(self):
+        return len(self.lp_fp_all)
+
+    def __getitem__(self, idx):
+        self.buffer_one(idx)
+        return self.lp_all[idx]

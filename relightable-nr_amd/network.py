@@ -2,8 +2,19 @@
 constructor / forward signatures, buffers and state-dict keys, computing on librnr_hip.so.
 
 In scope: TextureMapper, Rasterizer, RenderingNet, Interpolater, RaySampler, RayRenderer, LightingSH.
+In scope as "next" rows: LightingLP (HIP area resize instead of cv2), Mesh (host bookkeeping).
 Out of scope (raise on construction): DenseDeepGCN (train-time only; its cached output `v_feature` is loaded from the
-checkpoint and is dead at the output anyway), InterpolaterVertexAttr, Mesh, RaysLTChromLoss (loss), LightingLP (cv2).
+checkpoint and is dead at the output anyway), InterpolaterVertexAttr, RaysLTChromLoss (loss).
+With these, test_dnr.py and test_rnr.py construct every module they need, provided the inference flags keep
+DenseDeepGCN unused (test_rnr.py only builds it when the checkpoint lacks a cached `v_feature`).
+
+Intentional deviations from the reference classes (all invisible to the scripts' outputs):
+  * RenderingNet / Unet: the dead GCN pass is not executed (no second running-stat update from it); BatchNorm in train
+    mode takes whole-batch statistics like torch (the fused RNRPipeline uses per-view statistics = N calls with N = 1).
+  * LightingSH.reconstruct_lp detaches `coeff` (inference build: no gradient flows through the HIP kernels) and returns
+    [..., lp_recon_h, lp_recon_w, C]; a 2-D `init_coeff` is expanded to [num_lighting, nb, C] (the reference assigns
+    the 2-D tensor and breaks its own indexing); `l_samples` is computed from the coefficients at init.
+  * render.get_TBN_map does not raise on NaN by default (the reference's check costs three host syncs per view).
 """
 import numpy as np
 import torch
@@ -271,6 +282,83 @@ def _out_of_scope(name, why):
 
 DenseDeepGCN = _out_of_scope('DenseDeepGCN', 'train-time only; inference loads its cached output v_feature, which is dead at the output')
 InterpolaterVertexAttr = _out_of_scope('InterpolaterVertexAttr', 'unused at inference')
-Mesh = _out_of_scope('Mesh', 'only feeds the GCN')
 RaysLTChromLoss = _out_of_scope('RaysLTChromLoss', 'training loss')
-LightingLP = _out_of_scope('LightingLP', 'needs cv2 INTER_AREA resize of 1600x3200 probes; SURVEY §8(f) rank 2')
+
+
+class Mesh(nn.Module):
+    """network.py:355-388: vertex positions / normals of the low-resolution mesh with global_RT applied and the span /
+    centre statistics the scripts read (test_rnr.py:129-131 uses `num_vertex` only).  Host-side tensor bookkeeping."""
+
+    def __init__(self, obj_fp, global_RT=None):
+        super().__init__()
+        v_attr, _ = nr.load_obj(obj_fp, normalization=False, use_cuda=False)
+        v, vn = v_attr['v'].cpu(), v_attr['vn'].cpu()
+        self.num_vertex = v.shape[0]
+        self.v_orig, self.vn_orig = v.clone(), vn.clone()
+        self.span_orig = v.max(dim=0)[0] - v.min(dim=0)[0]
+        self.span_max_orig = self.span_orig.max()
+        self.center_orig = v.mean(dim=0)
+        if global_RT is not None:
+            g = global_RT.to(v.device).float()
+            v = torch.matmul(g, torch.cat((v, torch.ones(self.num_vertex, 1)), dim=1).t()).t()[:, :3]
+            vn = torch.nn.functional.normalize(torch.matmul(g[:3, :3], vn.t()).t(), dim=1)
+        self.register_buffer('v', v)
+        self.register_buffer('vn', vn)
+        self.span = v.max(dim=0)[0] - v.min(dim=0)[0]
+        self.span_max = self.span.max()
+        self.center = v.mean(dim=0)
+
+    def forward(self):
+        pass
+
+
+class LightingLP(nn.Module):
+    """network.py:631-699: light probes -> 1600 x 3200 area-averaged probes (`lps`) -> bilinear samples at the
+    `l_dir` directions (`l_samples`) -> SH projection (`fit_sh`).  The cv2 INTER_AREA resize, the bilinear taps and the
+    SH basis / projection run as HIP kernels (rnr_resize_area, rnr_interpolate_bilinear, rnr_sh_basis, rnr_sh_fit) on
+    `device` (default: the device of l_dir if it is a GPU tensor, else the current GPU); buffers keep the reference's
+    names, shapes and (CPU-by-default) placement.  cv2 parity of the resize is unpinned (no cv2 in this image)."""
+
+    def __init__(self, l_dir, num_lighting=1, num_channel=3, lp_dataloader=None, fix_params=False, lp_img_h=1600,
+                 lp_img_w=3200, device=None):
+        super().__init__()
+        self.register_buffer('l_dir', l_dir)
+        self.num_sample, self.num_lighting, self.num_channel = l_dir.shape[1], num_lighting, num_channel
+        self.fix_params, self.lp_img_h, self.lp_img_w = fix_params, lp_img_h, lp_img_w
+        if lp_dataloader is not None:
+            self.num_lighting = len(lp_dataloader)
+        self.register_buffer('l_samples_uv', render.spherical_mapping(l_dir))
+        self.l_samples = nn.Parameter(torch.zeros((self.num_lighting, self.num_sample, self.num_channel), dtype=torch.float32))
+        self._device_arg = device
+        if lp_dataloader is not None:
+            uv = self.l_samples_uv.to(self._dev).float()
+            lps = []
+            for idx, lp in enumerate(lp_dataloader):
+                img = lp['lp_img'][0].permute(1, 2, 0).float().contiguous().to(self._dev)             # [H,W,C]
+                img = ops.resize_area(img, lp_img_h, lp_img_w)                                          # network.py:667
+                x = (uv[0] * float(lp_img_w)).clamp(max=lp_img_w - 1).contiguous()                     # network.py:669
+                y = (uv[1] * float(lp_img_h)).clamp(max=lp_img_h - 1).contiguous()
+                self.l_samples.data[idx] = ops.interpolate_bilinear(img, x, y).to(self.l_samples.device)
+                lps.append(img.to(l_dir.device))
+            self.register_buffer('lps', torch.stack(lps))
+        if self.fix_params:
+            self.l_samples.requires_grad_(False)
+
+    @property
+    def _dev(self):
+        """GPU the HIP operators of this module run on (resolved on first use: constructing the module with
+        lp_dataloader=None needs no GPU, like the reference)."""
+        if self._device_arg is not None:
+            return torch.device(self._device_arg)
+        return self.l_dir.device if self.l_dir.is_cuda else torch.device('cuda', torch.cuda.current_device())
+
+    def forward(self, lighting_idx=None, is_lp=False):
+        src = self.lps if is_lp else self.l_samples
+        return src[None] if lighting_idx is None else src[lighting_idx][None]
+
+    def fit_sh(self, lmax):
+        """network.py:694-699: registers `sh_coeff` [num_lighting, (lmax+1)^2, num_channel]."""
+        dirs = self.l_dir.detach().t().contiguous().float().to(self._dev)
+        basis = ops.sh_basis(dirs, int(lmax))
+        coeff = sph_harm.fit_sh_coeff(samples=self.l_samples.detach().to(self._dev), sh_basis_val=basis)
+        self.register_buffer('sh_coeff', coeff.to(self.l_dir.device).to(self.l_dir.dtype))

@@ -1,7 +1,7 @@
 """nr.load_obj / load_mtl / load_textures (reference: neural_renderer/load_obj.py:1-209).
 
-One pass over the file instead of the reference's four; same outputs: float32 v / vn / vt and 0-based int32
-f_v_idx / f_vn_idx / f_vt_idx, triangles with `v/vt/vn` triplets (load_obj.py:168-175).  With load_texture=True the
+One native pass over the file bytes (csrc/objparse.hip behind the C ABI) instead of the reference's four Python passes;
+same outputs: float32 v / vn / vt and 0-based int32 f_v_idx / f_vn_idx / f_vt_idx, triangles (load_obj.py:168-175).  With load_texture=True the
 material colours / texture images of the .mtl are baked into per-face texture cubes by the HIP kernel behind
 neural_renderer.cuda.load_textures (images are read with PIL; the reference uses skimage.io.imread)."""
 import os
@@ -75,42 +75,49 @@ def load_textures(filename_obj, filename_mtl, texture_size, texture_wrapping='RE
     return textures
 
 
+def parse_obj_bytes(data):
+    """OBJ text (bytes) -> numpy arrays via the native reader of librnr_hip.so (rnr_obj_scan / rnr_obj_parse,
+    include/rnr_hip.h §4): v [nv,3], vn [nvn,3], vt [nvt,2] float32; f_v_idx, f_vt_idx, f_vn_idx [nf,3] int32 0-based
+    (index arrays of absent attributes are empty)."""
+    import ctypes
+    from rnr_amd import _lib
+    L = _lib.load()
+    cnt = _lib.RnrObjCounts()
+    _lib.check(L.rnr_obj_scan(data, len(data), ctypes.byref(cnt)))
+    nv, nvn, nvt, nf = cnt.num_vertices, cnt.num_normals, cnt.num_texcoords, cnt.num_faces
+    v, vn, vt = np.empty((nv, 3), np.float32), np.empty((nvn, 3), np.float32), np.empty((nvt, 2), np.float32)
+    fv = np.empty((nf, 3), np.int32)
+    fvt = np.empty((nf if nvt else 0, 3), np.int32)
+    fvn = np.empty((nf if nvn else 0, 3), np.int32)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else None
+    try:
+        _lib.check(L.rnr_obj_parse(data, len(data), ctypes.byref(cnt), ptr(v), ptr(vn), ptr(vt), ptr(fv), ptr(fvt), ptr(fvn)))
+    except _lib.RnrError as e:
+        raise ValueError(str(e)) from None          # the reference's parser raises ValueError on malformed numbers
+    return v, vn, vt, fv, fvt, fvn
+
+
 def load_obj(filename_obj, normalization=True, texture_size=4, load_texture=False, texture_wrapping='REPEAT',
              use_bilinear=True, use_cuda=True):
-    v, vn, vt, fv, fvt, fvn = [], [], [], [], [], []
+    """load_obj.py:108-209.  Geometry comes from the native one-pass reader (no Python loop over lines)."""
+    with open(filename_obj, 'rb') as fh:
+        data = fh.read()
+    v, vn, vt, fv, fvt, fvn = parse_obj_bytes(data)
     mtllib = None
-    with open(filename_obj) as fh:
-        for line in fh:
-            tok = line.split()
-            if not tok:
-                continue
-            key = tok[0]
-            if key == 'mtllib':
-                mtllib = tok[1]
-            if key == 'v':
-                v.append((float(tok[1]), float(tok[2]), float(tok[3])))
-            elif key == 'vn':
-                vn.append((float(tok[1]), float(tok[2]), float(tok[3])))
-            elif key == 'vt':
-                vt.append((float(tok[1]), float(tok[2])))
-            elif key == 'f':
-                parts = [p.split('/') for p in tok[1:]]
-                fv.append([int(p[0]) for p in parts])
-                if len(parts[0]) > 1 and parts[0][1] != '':
-                    fvt.append([int(p[1]) for p in parts])
-                if len(parts[0]) > 2:
-                    fvn.append([int(p[-1]) for p in parts])
+    if load_texture:
+        for line in data.split(b'\n'):
+            if line.startswith(b'mtllib'):
+                mtllib = line.split()[1].decode()
     dev = 'cuda' if use_cuda else 'cpu'
-    f32 = lambda a, w: torch.from_numpy(np.asarray(a, np.float32).reshape(-1, w)).to(dev)
-    i32 = lambda a: (torch.from_numpy(np.asarray(a, np.int32).reshape(-1, 3)) - 1).to(dev)
-    vertices = f32(v, 3)
+    f32 = lambda a: torch.from_numpy(a).to(dev)
+    vertices = f32(v)
     if normalization:   # load_obj.py:196-201
         vertices = vertices - vertices.min(0)[0][None, :]
         vertices = vertices / torch.abs(vertices).max()
         vertices = vertices * 2
         vertices = vertices - vertices.max(0)[0][None, :] / 2
-    v_attr = {'v': vertices, 'vn': f32(vn, 3) if vn else [], 'vt': f32(vt, 2) if vt else []}
-    f_attr = {'f_v_idx': i32(fv), 'f_vn_idx': i32(fvn), 'f_vt_idx': i32(fvt)}
+    v_attr = {'v': vertices, 'vn': f32(vn) if len(vn) else [], 'vt': f32(vt) if len(vt) else []}
+    f_attr = {'f_v_idx': f32(fv), 'f_vn_idx': f32(fvn), 'f_vt_idx': f32(fvt)}
     if load_texture:
         if mtllib is None:
             raise Exception('Failed to load textures.')

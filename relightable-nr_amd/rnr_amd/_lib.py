@@ -26,6 +26,10 @@ class RnrGbuffer(ctypes.Structure):
                                         'position_map_cam']]
 
 
+class RnrObjCounts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_long) for n in ['num_vertices', 'num_normals', 'num_texcoords', 'num_faces']]
+
+
 class RnrRays(ctypes.Structure):
     _fields_ = [('pivots_spec_host', c_void_p), ('pivots_diff_host', c_void_p), ('num_spec', c_int),
                 ('num_diff', c_int)]
@@ -88,6 +92,9 @@ SIGNATURES = {
     'rnr_sh_fit': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_interpolate_bilinear': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p]),
+    'rnr_resize_area': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rnr_obj_scan': (c_int, [ctypes.c_char_p, c_size_t, P(RnrObjCounts)]),
+    'rnr_obj_parse': (c_int, [ctypes.c_char_p, c_size_t, P(RnrObjCounts)] + [c_void_p] * 6),
     'rnr_view_dir_map': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_tbn_map': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_ray_sampler': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

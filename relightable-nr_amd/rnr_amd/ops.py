@@ -373,6 +373,19 @@ def interpolate_bilinear(data, x, y, want_taps=False):
 
 
 @_device_op
+def resize_area(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_AREA) for a channel-last float image [H,W,C] -> [out_h,out_w,C]
+    (network.py:667; restated from OpenCV's algorithm, see include/rnr_hip.h)."""
+    L = _lib.load()
+    _chk(img, 'img')
+    if img.dim() != 3:
+        raise RuntimeError('img must be [H,W,C]')
+    out = torch.empty(int(out_h), int(out_w), img.shape[2], dtype=torch.float32, device=img.device)
+    check(L.rnr_resize_area(_ptr(img), _ptr(out), img.shape[0], img.shape[1], int(out_h), int(out_w), img.shape[2], _stream()))
+    return out
+
+
+@_device_op
 def nchw_to_nhwc(x, c_pad):
     L = _lib.load()
     _chk(x, 'x')

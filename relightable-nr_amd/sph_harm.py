@@ -20,13 +20,19 @@ def sph2cart(azimuth, elevation, r):
     return r * ce * m.cos(azimuth), r * ce * m.sin(azimuth), r * m.sin(elevation)
 
 
-def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device='cuda'):
+def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None):
     """sph_harm.py:41-71.  directions [n,3] (numpy or tensor) or azi/pol in degrees -> np.ndarray [n,(lmax+1)^2]
-    (float64 container like the reference; values carry float32 precision, which is what every caller casts to)."""
+    (float64 container like the reference; values carry float32 precision, which is what every caller casts to).
+    Runs on the device of `directions` when that is a GPU tensor, else on `device` (default: the current GPU)."""
     if directions is None:
         a, p = np.deg2rad(np.asarray(azi, np.float64)), np.deg2rad(np.asarray(pol, np.float64))
         directions = np.stack([np.sin(p) * np.cos(a), np.sin(p) * np.sin(a), np.cos(p)], -1)
-    d = torch.as_tensor(np.asarray(directions, np.float32)).contiguous().to(device)
+    if torch.is_tensor(directions) and directions.is_cuda:
+        d = directions.detach().float().contiguous()
+    else:
+        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        src = directions.detach().cpu().numpy() if torch.is_tensor(directions) else directions
+        d = torch.as_tensor(np.asarray(src, np.float32)).contiguous().to(dev)
     return ops.sh_basis(d, int(lmax)).cpu().numpy().astype(np.float64)
 
 

@@ -2,6 +2,7 @@
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -74,6 +75,42 @@ def test_load_obj_matches_reference_parser(golden, tmp_path):
         assert f_attr[k].dtype == torch.int32 and np.array_equal(f_attr[k].numpy(), g['loaded_' + k]), k
 
 
+def test_native_obj_reader_edge_cases(golden, tmp_path):
+    """csrc/objparse.hip (rnr_obj_scan / rnr_obj_parse) vs the reference parser's output (fixture `obj_edge_cases`,
+    load_obj.py:108-209 run in the build container) on awkwardly formatted OBJ text: bit-identical float32 / int32."""
+    import neural_renderer as nr
+    g = golden('obj_edge_cases')
+    for name in sorted({k.split(':')[0] for k in g.files}):
+        p = str(tmp_path / (name + '.obj'))
+        with open(p, 'wb') as fh:
+            fh.write(g[name + ':text'].tobytes())
+        va, fa = nr.load_obj(p, normalization=False, use_cuda=False)
+        for k in ['v', 'vn', 'vt']:
+            assert va[k].dtype == torch.float32
+            assert np.array_equal(va[k].numpy().view(np.uint32), g[name + ':' + k].view(np.uint32)), (name, k)
+        for k in ['f_v_idx', 'f_vn_idx', 'f_vt_idx']:
+            assert fa[k].dtype == torch.int32 and np.array_equal(fa[k].numpy(), g[name + ':' + k]), (name, k)
+
+
+def test_native_obj_reader_errors_and_absent_attributes(tmp_path):
+    """Own behaviour where the reference parser simply crashes: a file without vt lines gives empty vt / f_vt_idx
+    (the reference dies in np.vstack([]), load_obj.py:172); quads and malformed numbers raise ValueError with the line."""
+    from neural_renderer.load_obj import parse_obj_bytes
+    v, vn, vt, fv, fvt, fvn = parse_obj_bytes(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 3//1 2//1 1//1\n")
+    assert v.shape == (3, 3) and vn.shape == (1, 3) and vt.shape == (0, 2) and fvt.shape == (0, 3)
+    assert np.array_equal(fv, [[0, 1, 2], [2, 1, 0]]) and np.array_equal(fvn, np.zeros((2, 3), np.int32))
+    v, vn, vt, fv, fvt, fvn = parse_obj_bytes(b"")
+    assert v.shape == (0, 3) and fv.shape == (0, 3)
+    v, vn, vt, fv, fvt, fvn = parse_obj_bytes(b"v 1 2 3")           # no trailing newline
+    assert np.array_equal(v, [[1, 2, 3]])
+    with pytest.raises(ValueError, match='line 4'):
+        parse_obj_bytes(b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3 1\n")
+    with pytest.raises(ValueError, match='line 2'):
+        parse_obj_bytes(b"v 0 0 0\nv 1 x 0\n")
+    with pytest.raises(ValueError, match='texcoord'):
+        parse_obj_bytes(b"v 0 0 0\nvt 0 0\nf 1 1 1\n")
+
+
 def test_module_function_names():
     import camera, misc, render, sph_harm, network
     for mod, names in [(camera, ['get_view_dir_map', 'get_reflect_dir', 'RT_from_pos_lookat', 'get_spiral']),
@@ -85,7 +122,12 @@ def test_module_function_names():
         for n in names:
             assert hasattr(mod, n), (mod.__name__, n)
     with pytest.raises(NotImplementedError):
-        network.LightingLP(None)
+        network.DenseDeepGCN()
+    # LightingLP without probes is pure bookkeeping (network.py:631-664): constructible on a CPU-only host
+    l_dir = torch.nn.functional.normalize(torch.randn(3, 32, generator=torch.Generator().manual_seed(0)), dim=0)
+    lp = network.LightingLP(l_dir, num_lighting=2, num_channel=3)
+    assert tuple(lp.l_samples.shape) == (2, 32, 3) and tuple(lp.l_samples_uv.shape) == (2, 32)
+    assert tuple(lp(1).shape) == (1, 32, 3) and set(lp.state_dict()) == {'l_samples', 'l_dir', 'l_samples_uv'}
 
 
 def test_host_helpers_match_oracle():

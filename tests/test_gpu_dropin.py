@@ -324,3 +324,34 @@ def test_renderer_look_at_modes():
         assert rgb.shape == (1, 3, 64, 64) and float((rgb.cpu().sum(1) > 0).float().mean()) > 0.05
         out = r(v, f, tex)
         assert len(out) == 8 and torch.allclose(out[0], rgb) and torch.allclose(out[2], sil)
+
+
+def test_extension_accepts_float64(golden):
+    """rasterize_cuda_kernel.cu:614 dispatches float / double; the drop-in extension accepts float64 buffers (computed by
+    the float32 kernels on converted copies, written back in place, inputs untouched) and rejects mixed scalar types."""
+    import warnings
+    import neural_renderer.cuda.rasterize as ext
+    g = golden('raster_soup64')
+    S, far = int(g['image_size']), float(g['far'])
+    f64 = T(g['faces']).double().to(DEV)
+    f64_before = f64.clone()
+    B, nf = f64.shape[:2]
+    fim = torch.full((B, S, S), -1, dtype=torch.int32, device=DEV)
+    wm = torch.zeros(B, S, S, 3, dtype=torch.float64, device=DEV)
+    dm = torch.full((B, S, S), far, dtype=torch.float64, device=DEV)
+    fivm = torch.zeros(B, S, S, 3, 3, dtype=torch.float64, device=DEV)
+    finv = torch.zeros_like(f64)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ext._warned[0] = False
+        out = ext.forward_face_index_map(f64, fim, wm, dm, fivm, finv, S, 0.0, far, 1, 1, 1)
+    assert any('float64' in str(x.message) for x in w)
+    assert out[1] is wm and out[2] is dm and out[3] is fivm and wm.dtype == torch.float64
+    assert torch.equal(f64, f64_before)
+    assert np.array_equal(fim.cpu().numpy(), g['face_index_map'])
+    ok = np.isfinite(g['weight_map'])
+    assert np.array_equal(wm.cpu().numpy()[ok], g['weight_map'].astype(np.float64)[ok])
+    assert np.array_equal(dm.cpu().numpy(), g['depth_map'].astype(np.float64))
+    with pytest.raises(RuntimeError):
+        ext.forward_face_index_map(f64, fim, wm.float(), dm, fivm, finv, S, 0.0, far, 1, 1, 1)
+

@@ -350,11 +350,11 @@ def test_gbuffer_vs_reference_module(golden):
             if k == 'uv_map':
                 d = np.minimum(d, 1.0 - d)
             assert d.max() < tol * max(1.0, np.abs(ref[ok]).max()), (k, d.max())
-    # (C) the reference's own projected vertices (fixture `v_uvz`, 13th element of the 14-tuple, network.py:216) fed to the
+    # (C) the reference's own projected NDC vertices (fixture `v_ndc`, captured at the nr.Renderer boundary) fed to the
     # HIP kernel: no host matmul in between, so the integer maps must equal the reference golden EXACTLY and the
     # interpolated maps to float rounding (pointwise three-term sums in a different association)
     for i in range(2):
-        v_ref = torch.from_numpy(g['view%d_v_uvz' % i]).contiguous().to(dev)
+        v_ref = torch.from_numpy(g['view%d_v_ndc' % i]).contiguous().to(dev)
         gb = ops.rasterize_gbuffer(mesh, v_ref, pose[i:i + 1].to(dev), S)
         torch.cuda.synchronize()
         c = lambda k: gb[k][0].cpu().numpy()

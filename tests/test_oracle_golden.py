@@ -157,6 +157,37 @@ def test_rasterizer_module(golden):
     assert (g['view0_alpha'] > 0).mean() > 0.2      # the sphere is actually visible (winding/cull sanity)
 
 
+def test_rasterizer_module_on_reference_ndc_vertices(golden):
+    """Same fixture, but the reference's own projected NDC vertices (captured at the nr.Renderer boundary) go straight
+    into the oracle: no host matmul in between, hence the float maps must agree to the last bits of pointwise math."""
+    g = golden('rasterizer_module64')
+    mesh = _mesh(g)
+    mesh['v'], mesh['vn'] = T(g['buf_vertices'])[0], T(g['buf_vertices_normals'])[0]
+    for i in range(2):
+        out = orc.rasterizer_forward(mesh, T(g['proj'][i:i + 1]), T(g['pose'][i:i + 1]), int(g['image_size']),
+                                     v_uvz_ndc=T(g['view%d_v_ndc' % i]))
+        assert torch.equal(out['face_index_map'], T(g['view%d_face_index_map' % i]))
+        assert torch.equal(out['v_uvz'], T(g['view%d_v_uvz' % i]))
+        for k in ['uv_map', 'weight_map', 'normal_map', 'position_map', 'depth']:
+            ref = T(g['view%d_%s' % (i, k)])
+            assert torch.allclose(out[k], ref, atol=1e-6, rtol=1e-6), (k, (out[k] - ref).abs().max())
+
+
+def test_resize_area_restatement():
+    """oracle.resize_area (cv2 INTER_AREA restated; cv2 parity unpinned): integer ratios == plain box mean; constant
+    images stay constant for every ratio (weights sum to 1); shrink weights partition the source exactly."""
+    rng = np.random.RandomState(3)
+    img = rng.rand(24, 40, 3).astype(np.float32)
+    assert np.abs(orc.resize_area(img, 6, 10) - img.reshape(6, 4, 10, 4, 3).mean((1, 3))).max() < 1e-6
+    assert np.abs(orc.resize_area(img, 24, 20) - img.reshape(24, 20, 2, 3).mean(2)).max() < 1e-6
+    for hw in [(7, 11), (23, 39), (48, 80), (30, 20), (5, 64)]:
+        const = orc.resize_area(np.full((24, 40, 2), 0.75, np.float32), *hw)
+        assert np.abs(const - 0.75).max() < 1e-6, hw
+    out = orc.resize_area(img, 7, 11)
+    assert abs(float(out.mean()) - float(img.mean())) < 1e-6        # fractional cells tile the source: mean preserved
+    assert np.array_equal(orc.resize_area(img, 24, 40), img)         # identity
+
+
 def test_interpolate_bilinear(golden):
     g = golden('bilinear')
     out = orc.interpolate_bilinear(T(g['data']), T(g['x']), T(g['y']))
