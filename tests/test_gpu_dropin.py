@@ -347,7 +347,7 @@ def test_extension_accepts_float64(golden):
         out = ext.forward_face_index_map(f64, fim, wm, dm, fivm, finv, S, 0.0, far, 1, 1, 1)
     assert any('float64' in str(x.message) for x in w)
     assert out[1] is wm and out[2] is dm and out[3] is fivm and wm.dtype == torch.float64
-    assert torch.equal(f64, f64_before)
+    assert torch.equal(f64.view(torch.int64), f64_before.view(torch.int64))      # bitwise: the soup holds NaN / inf vertices
     assert np.array_equal(fim.cpu().numpy(), g['face_index_map'])
     ok = np.isfinite(g['weight_map'])
     assert np.array_equal(wm.cpu().numpy()[ok], g['weight_map'].astype(np.float64)[ok])

@@ -136,8 +136,8 @@ def test_dropin_unet_whole_batch_batchnorm():
             m = h.mean((0, 2, 3)); v = h.var((0, 2, 3), unbiased=False)
             n = h.numel() / h.shape[1]
             run[key] = (m, v * n / (n - 1))
-            return (h - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-5) * w(key + '.weight')[None, :, None, None] \\
-                + w(key + '.bias')[None, :, None, None]
+            hn = (h - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-5)
+            return hn * w(key + '.weight')[None, :, None, None] + w(key + '.bias')[None, :, None, None]
         cr = lambda h, k, s=1, b=None: F.conv2d(F.pad(h, (1, 1, 1, 1), mode='reflect'), w(k), b, stride=s)
 
         def block(h, path, depth):
