@@ -44,7 +44,7 @@ def parse():
                     help='let the out layer skip all-background pixel tiles in the timed loop (frames are bit-identical; '
                          'off by default so that `value` is the full RenderingNet on every pixel; the skip-enabled rate '
                          'is reported beside it as with_background_tile_skip)')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6', 'f16x3'],
                     help="conv arithmetic of the timed loop: exact fp32 MFMA (default, the headline) or fp32 emulated on the bf16 "
                          "matrix cores (RNR_CONV_F32_EMU_BF16X6)")
     ap.add_argument('--pmc-file', default=None,

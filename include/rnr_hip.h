@@ -242,6 +242,17 @@ typedef struct rnr_conv_desc {
  * 2^127 (the leading bf16 term of a larger value rounds to infinity); residual terms in fp32's subnormal range are
  * flushed, which only costs precision below 1e-38. */
 #define RNR_CONV_F32_EMU_BF16X6 2
+/* fp32 emulation on the fp16 matrix cores: every operand is split into TWO fp16 terms (22 significand bits, relative
+ * representation error <= 2^-23) and the three leading partial products (hh, hl, lh) are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_f16: 5.3x fewer MFMA cycles than the exact-fp32 kernel, half of bf16x6.  Measured error against a
+ * float64 convolution is below the exact-fp32 kernel's on every U-Net layer shape (fewer accumulator roundings outweigh
+ * the two missing significand bits; tests/test_gpu_unet.py).  Weights are pre-scaled per layer by a power of two at pack
+ * time (undone exactly in the epilogue), so any finite weights are fine; activations must satisfy
+ * |act(scale * x + shift)| < 65504 — true for BatchNorm outputs and bounded network inputs; values below 2^-14 keep an
+ * absolute precision of 2^-25 (fp16 subnormals are honoured by the MFMA).  Same packing / fallback rules as BF16X6;
+ * the two flags are mutually exclusive. */
+#define RNR_CONV_F32_EMU_F16X3 4
+#define RNR_CONV_F32_EMU_ANY (RNR_CONV_F32_EMU_BF16X6 | RNR_CONV_F32_EMU_F16X3)
 
 /* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
 size_t rnr_packed_weight_floats(const rnr_conv_desc* d);

@@ -17,9 +17,11 @@
 //                 one fp64 atomic per channel per workgroup) for the next BatchNorm's batch statistics.
 //
 // Kernels: conv_halo_kernel (LDS-halo tiles, exact fp32: every map >= 32 px wide), conv_mfma_kernel (tap-by-tap gather:
-// the small maps), conv_halo_emu_kernel (opt-in: fp32 emulated on the bf16 matrix cores, RNR_CONV_F32_EMU_BF16X6).
+// the small maps), conv_halo_emu_kernel (opt-in: fp32 emulated on the 16-bit matrix cores, RNR_CONV_F32_EMU_BF16X6 / _F16X3).
 // make_plan() picks the kernel, the tile shape (256x64, 256x80, 128x128 or 256x128 rows x columns) and the split-K depth.
 #include "rnr_internal.h"
+
+#include <algorithm>
 
 namespace rnr {
 
@@ -715,19 +717,27 @@ conv_halo_kernel(const ConvParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32 emulation on the bf16 matrix cores ("bf16x6").
+// fp32 emulation on the 16-bit matrix cores (opt-in; gfx950's fp32-input MFMA runs at 1/16 of the 16-bit rate).
 //
-// A float is split exactly into three bf16 terms, x = h + m + l (8 + 8 + 8 mantissa bits, each the round-to-nearest
-// bf16 of the running remainder), and a product keeps the six partial products of weight >= 2^-16:
-//   a*b ~= ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm        (dropped: am*bl, al*bm, al*bl <= 2^-24 |a*b|)
-// Every partial product of two bf16 is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result
-// differs from the fp32 MFMA path only by terms of the size of fp32's own rounding (measured: tests/test_gpu_unet.py,
-// scripts/emu_accuracy.py) while one 16-channel chunk costs 6 x 32 = 192 MFMA cycles instead of 8 x 64 = 512.
-// Same tiling, halo staging, fused BatchNorm prologue / statistics epilogue as conv_halo_kernel (KIND 0 and 2 only).
-// LDS images of a 16-channel chunk: [3 terms][2 k-halves][X pixels or columns][8 bf16] — an MFMA lane (x, k-half)
-// reads its 8 channels of one term as one lane-consecutive ds_read_b128; the packed weights hold the same image.
-// One LDS copy of the halo; the next chunk's halo rides in registers across the taps (as the 4x4-s2 kernel does),
-// which keeps three workgroups per CU.
+// Every conv operand is split into a few 16-bit terms whose sum is (nearly) the fp32 value, the partial products of
+// significant weight are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}; every partial product of two 16-bit
+// terms is exact in fp32.  Two formats:
+//   FMT 0 "bf16x6": x = h + m + l EXACTLY, three bf16 terms (8 + 8 + 8 significand bits, each the round-to-nearest bf16
+//          of the running remainder); six products of weight >= 2^-16: hh, hm, mh, hl, lh, mm (dropped: <= 2^-24 |ab|).
+//          6 x 32 = 192 MFMA cycles per 16-channel chunk instead of 8 x 64 = 512.
+//   FMT 1 "f16x3":  x ~= h + l, two fp16 terms (11 + 11 significand bits: relative representation error <= 2^-23, a
+//          quarter of an fp32 ulp... of a 22-bit significand); three products hh, hl, lh (dropped ll <= 2^-22 |ab|).
+//          3 x 32 = 96 MFMA cycles per chunk.  Fewer accumulator roundings (3 per 16 channels instead of 8 per 16 in the
+//          exact-fp32 chain) more than pay for the two dropped significand bits: measured error vs float64 is BELOW the
+//          exact-fp32 kernel's on every layer shape of the U-Net (tests/test_gpu_unet.py).  fp16's narrow
+//          exponent is handled as follows: the MFMA honours fp16 subnormals (scripts/micro/mfma_f16_denorm.hip), so a
+//          residual term below 2^-14 keeps an absolute precision of 2^-25; weights (typically 1e-2, whose residuals
+//          would all be subnormal) are pre-multiplied at pack time by a per-layer power of two that brings max|w| into
+//          [2^12, 2^13) and the accumulators are multiplied by its inverse in the epilogue (exact); activations are
+//          used as they are: valid for |act(scale*x+shift)| < 65504 (a BatchNorm output or a bounded input).
+// LDS image of a 16-channel halo chunk: [NT terms][2 k-halves][pixels][8 x 16 bit] — an MFMA lane (pixel, k-half) reads
+// its 8 channels of one term as one lane-consecutive ds_read_b128; the packed weights hold the same image per
+// (parity, tap, chunk): [NT terms][2 k-halves][wstride columns][8 x 16 bit].
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -744,9 +754,59 @@ __device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned& h, un
     h = __builtin_bit_cast(unsigned, hb); m = __builtin_bit_cast(unsigned, mb); l = __builtin_bit_cast(unsigned, lb);
 }
 
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ void __launch_bounds__(CTHREADS, WM * WN <= 4 ? RNR_HALO_WAVES : 2)
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+
+// x ~= h + l, two fp16 terms (round-to-nearest; subnormal residuals keep 2^-25 absolute precision)
+__device__ __forceinline__ void split_f16x2(float x0, float x1, unsigned& h, unsigned& l) {
+    const floatx2 v = {x0, x1};
+    const halfx2 hb = __builtin_convertvector(v, halfx2);
+    const floatx2 r1 = v - __builtin_convertvector(hb, floatx2);
+    const halfx2 lb = __builtin_convertvector(r1, halfx2);
+    h = __builtin_bit_cast(unsigned, hb); l = __builtin_bit_cast(unsigned, lb);
+}
+
+template <int FMT> struct EmuFmt;
+template <> struct EmuFmt<0> {
+    static constexpr int NT = 3;
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ floatx16 mfma(vec8 a, vec8 b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(float x0, float x1, unsigned (&t)[3]) { split_bf16x3(x0, x1, t[0], t[1], t[2]); }
+};
+template <> struct EmuFmt<1> {
+    static constexpr int NT = 2;
+    typedef halfx8 vec8;
+    static __device__ __forceinline__ floatx16 mfma(vec8 a, vec8 b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split(float x0, float x1, unsigned (&t)[2]) { split_f16x2(x0, x1, t[0], t[1]); }
+};
+constexpr int EMU_HEADER_BYTES = 64;     // packed emulation image: [0] float 2^-k (accumulator rescale), [1] float k, [2] uint bits of max|w|
+
+// ------------------------------------------------------------------------------------------------
+// conv_halo_emu_kernel<FMT, ...>: tiling, fused BatchNorm prologue, halo image and statistics epilogue as in
+// conv_halo_kernel (the exact-fp32 kernel); how the operands travel:
+//   * weights never touch LDS: an MFMA lane's B operand (8 bf16 of one column, one k-half, one term) is 16 contiguous
+//     bytes of the packed image, lanes of a wave are consecutive columns, so a tap's weights are 3*WN coalesced
+//     global_load_dwordx4 per wave straight into the operand registers, prefetched one tap ahead (L2 / L1 serve the
+//     re-reads of the other row-waves and workgroups).  No LDS-DMA issue cost, no weight tile to guard;
+//   * hence no barrier per tap: the only LDS hazard left is the halo swap, and the halo is double-buffered in LDS
+//     (the space the weight tiles used to take), so ONE barrier per 16-channel chunk (every TAPS * 6 * WM * WN MFMAs per
+//     wave) suffices (the first generation of this kernel staged weight tiles by LDS-DMA with a barrier per tap: 5 %
+//     slower, profiles/README.md);
+//   * the next chunk's halo is fetched, normalised, split into its three bf16 terms and written to the other buffer
+//     in slices spread over the taps (a slice is loaded during tap t and converted during tap t+1), i.e. the VALU work
+//     of the split sits in the issue slots between MFMAs instead of in a burst between two barriers.
+// Two workgroups (2 x 4 waves) per CU: two waves per SIMD cover each other's operand waits.
+// ------------------------------------------------------------------------------------------------
+template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(CTHREADS, 2)
 conv_halo_emu_kernel(const ConvParams P) {
+    typedef EmuFmt<FMT> F;
+    typedef typename F::vec8 vec8;
+    constexpr int NT = F::NT;
     static_assert(WAVES_M * WAVES_N == 4 && BK == 16, "four waves, 16-channel chunks");
     constexpr int TW = 32, TH = WAVES_M * WM;
     constexpr int BN = WAVES_N * WN * 32;
@@ -756,17 +816,14 @@ conv_halo_emu_kernel(const ConvParams P) {
     constexpr int HP = HWD * HHT;
     constexpr int ASLOTS = HP * 4;
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
-    constexpr int BNL = (BN + 63) / 64 * 64;                  // columns of the LDS weight image: whole 64-lane DMA pieces
-    constexpr int APL = 2 * HP * 16, BPL = 2 * BNL * 16;      // bytes per term plane (two k-halves)
-    constexpr int ACHB = 3 * APL, BCHB = 3 * BPL;             // bytes per chunk image
+    constexpr int SPT = (APT + TAPS - 1) / TAPS;              // halo slots a thread converts per tap
+    constexpr int NGROUPS = (APT + SPT - 1) / SPT;            // <= TAPS
+    constexpr int APL = 2 * HP * 16;                          // bytes per term plane (two k-halves)
+    constexpr int ACHB = NT * APL;                            // bytes per halo image
     constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;        // halo pixels between consecutive output rows
-    constexpr int RUNS = (BN + 63) / 64;
-    constexpr int NPB = 6 * RUNS;                             // DMA pieces per weight tile: (term, k-half, 64-column run)
-    constexpr int BPT = (NPB + 3) / 4;
 
     extern __shared__ __attribute__((aligned(16))) char smemb[];
-    char* As = smemb;                   // [ACHB]
-    char* Bs = smemb + ACHB;            // [2][BCHB]
+    char* As = smemb;                   // [2][ACHB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -791,9 +848,7 @@ conv_halo_emu_kernel(const ConvParams P) {
     float smask[KIND == 2 ? APT : 1];
 #pragma unroll
     for (int j = 0; j < APT; j++) {
-        // slots past the halo only fetch (a valid address, the value is never stored): storing them as duplicates of an
-        // earlier slot, as conv_halo_kernel does, produced sporadically corrupted 16-lane groups in this kernel's
-        // three-plane ds_write_b64 pattern on gfx950 (tests/test_gpu_unet.py::test_emulation_halo_swap_stress)
+        // slots past the halo only fetch (a valid address); they are never stored (every LDS slot is written once)
         int s = tid + CTHREADS * j;
         if (s >= ASLOTS) s -= ASLOTS;
         const int hp = s >> 2;
@@ -818,13 +873,18 @@ conv_halo_emu_kernel(const ConvParams P) {
     const int c_begin = split * per_split;
     const int c_end = min(nchunks, c_begin + per_split);
 
-    struct ChunkSrc { const float* base; unsigned C; int act; float4 sc, sh; };
+    // Global operands go through buffer loads: a wave-uniform base (resource + scalar offset) plus ONE 32-bit per-lane
+    // offset.  With flat 64-bit addresses the unrolled tap loop keeps a strength-reduced pointer pair per (tap, term)
+    // alive across the chunk loop and spills.
+    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; float4 sc, sh; };
     auto chunk_src = [&](int c) {
         ChunkSrc cs;
         const int s = c < P.chunks0 ? 0 : 1;
         const int cc = (c - (s ? P.chunks0 : 0)) * BK;
         cs.C = (unsigned)P.src_c[s];
-        cs.base = P.src_data[s] + (size_t)n * P.H * P.W * cs.C + cc;
+        cs.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src_data[s] + (size_t)n * P.H * P.W * cs.C), 0,
+                                                    0x7fffffff, 0x27000);
+        cs.soff = (unsigned)cc * 4u;
         cs.act = P.src_act[s];
         cs.sc = make_float4(1.f, 1.f, 1.f, 1.f);
         cs.sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -833,47 +893,38 @@ conv_halo_emu_kernel(const ConvParams P) {
         return cs;
     };
     auto load_a = [&](const ChunkSrc& cs, int j) {
-        const unsigned voff = spix[j] * cs.C + 4u * (unsigned)q;
-        return *reinterpret_cast<const float4*>(cs.base + voff);
+        const unsigned voff = (spix[j] * cs.C + 4u * (unsigned)q) * 4u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, (int)voff, (int)cs.soff, 0));
     };
-    auto store_a = [&](const ChunkSrc& cs, float4 v, int j) {
+    auto store_a = [&](const ChunkSrc& cs, float4 v, int j, char* img) {
         float x = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
         float y = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
         float z = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
         float w = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
         if (KIND == 2) { x *= smask[j]; y *= smask[j]; z *= smask[j]; w *= smask[j]; }
-        unsigned h0, m0, l0, h1, m1, l1;
-        split_bf16x3(x, y, h0, m0, l0);
-        split_bf16x3(z, w, h1, m1, l1);
-        char* a = As + sdst[j];
-        *reinterpret_cast<uint2*>(a) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(a + APL) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(a + 2 * APL) = make_uint2(l0, l1);
+        unsigned t0[NT], t1[NT];
+        F::split(x, y, t0);
+        F::split(z, w, t1);
+        char* a = img + sdst[j];
+#pragma unroll
+        for (int term = 0; term < NT; term++) *reinterpret_cast<uint2*>(a + term * APL) = make_uint2(t0[term], t1[term]);
     };
-    // weight tile: packed image per (parity, tap, chunk) = [3 terms][2 k-halves][wstride][8 bf16]
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned bvoff[BPT];
-    int blds[BPT];
-    bool blive[BPT];
+    // weights: packed image per (parity, tap, chunk) = [NT terms][2 k-halves][wstride][8 x 16 bit] behind a 64-byte header
+    const char* wimg = reinterpret_cast<const char*>(P.weight_emu) + EMU_HEADER_BYTES;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wimg), 0, 0x7fffffff, 0x27000);
+    const unsigned tile_bytes = (unsigned)(NT * 32) * (unsigned)P.wstride;
+    unsigned bvoff[NT];
 #pragma unroll
-    for (int b = 0; b < BPT; b++) {
-        const int pc = wave_u + 4 * b;
-        const int g = pc / RUNS, run = pc - g * RUNS;           // g = term * 2 + k-half
-        bvoff[b] = ((unsigned)g * (unsigned)P.wstride + (unsigned)(n0 + 64 * run + lane)) * 16u;
-        blds[b] = (g * BNL + 64 * run) * 16;
-        blive[b] = pc < NPB;
-    }
-    const char* wemu = reinterpret_cast<const char*>(P.weight_emu);
-    auto dma_b = [&](int c, int t, int buf) {
-        const char* wt = wemu + ((size_t)(par * TAPS + t) * nchunks + c) * (96 * (size_t)P.wstride);
+    for (int term = 0; term < NT; term++)
+        bvoff[term] = ((unsigned)(term * 2 + h) * (unsigned)P.wstride + (unsigned)(n0 + wn0 + l31)) * 16u;
+    auto load_b = [&](vec8 (&dst)[NT][WN], int c, int t) {
+        const unsigned soff = (unsigned)((par * TAPS + t) * nchunks + c) * tile_bytes;      // wave-uniform
 #pragma unroll
-        for (int b = 0; b < BPT; b++) {
-            if (NPB % 4 == 0 || blive[b]) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + bvoff[b]),
-                                                 (__attribute__((address_space(3))) void*)(Bs + buf * BCHB + blds[b]),
-                                                 16, 0, 0);
-            }
-        }
+        for (int term = 0; term < NT; term++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+                dst[term][j] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(bvoff[term] + 512u * j),
+                                                                                           (int)soff, 0));
     };
 
     floatx16 acc[WM][WN];
@@ -885,80 +936,97 @@ conv_halo_emu_kernel(const ConvParams P) {
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
     const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
-    const char* a_lane = As + (h * HP + wrow + l31) * 16;
-    const char* b_lane = Bs + (h * BNL + wn0 + l31) * 16;
+    const int a_lane_off = (h * HP + wrow + l31) * 16;
 
+    vec8 b[2][NT][WN];
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
+        load_b(b[0], c_begin, 0);
 #pragma unroll
         for (int j = 0; j < APT; j++)
-            if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j);
-        dma_b(c_begin, 0, 0);
+            if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j, As);
     }
     __syncthreads();
-    int step = 0;
-    for (int c = c_begin; c < c_end; c++) {
+    int cur = 0;
+    for (int c = c_begin; c < c_end; c++, cur ^= 1) {
         const bool next_chunk = c + 1 < c_end;
-        ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
-        // the whole next halo is requested up front and parked in registers; the tap loop is NOT unrolled: unrolled, the
-        // scheduler hoists the LDS reads of later taps until the register file spills
-        float4 av_all[APT];
-#ifndef RNR_ABLATE_EMU_NOHALO
-        if (next_chunk) {
+        const ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
+        const char* a_rd = As + cur * ACHB + a_lane_off;
+        char* a_wr = As + (cur ^ 1) * ACHB;
+        float4 av[2][SPT];
 #pragma unroll
-            for (int j = 0; j < APT; j++) av_all[j] = load_a(csn, j);
-        }
-#endif
-#pragma unroll 1
-        for (int t = 0; t < TAPS; t++, step++) {
-            const bool more = next_chunk || t < TAPS - 1;
-#ifndef RNR_ABLATE_EMU_NODMA
-            if (more) {
-                if (t < TAPS - 1) dma_b(c, t + 1, (step + 1) & 1); else dma_b(c + 1, 0, (step + 1) & 1);
+        for (int t = 0; t < TAPS; t++) {
+            // ---- operands of the NEXT tap / chunk are requested before this tap's MFMAs ----
+            if (t < TAPS - 1) load_b(b[(t + 1) & 1], c, t + 1);
+            else if (next_chunk) load_b(b[TAPS & 1], c + 1, 0);
+#ifndef RNR_ABLATE_EMU_NOHALO
+            if (next_chunk) {
+                if (t < NGROUPS) {
+#pragma unroll
+                    for (int u = 0; u < SPT; u++)
+                        if (t * SPT + u < APT) av[t & 1][u] = load_a(csn, t * SPT + u);
+                }
+                if (t >= 1 && t - 1 < NGROUPS) {
+#pragma unroll
+                    for (int u = 0; u < SPT; u++) {
+                        const int j = (t - 1) * SPT + u;
+                        if (j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[(t - 1) & 1][u], j, a_wr);
+                    }
+                }
             }
 #endif
             int aoff;
-            if (KIND == 0) { const int ky = (t * 11) >> 5; aoff = ky * HWD + (t - 3 * ky); }      // t / 3 for t < 9
+            if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
             else if (KIND == 1) aoff = (t >> 2) * HWD + (t & 1) * (HWD / 2) + ((t & 3) >> 1);
             else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
-            const char* a_s = a_lane + aoff * 16;
-            const char* b_s = b_lane + (step & 1) * BCHB;
-            // all three weight terms stay live, the halo terms are fetched one at a time (l, m, h): 32 operand
-            // registers instead of 48; partial products still run smallest to largest per halo term
-            bf16x8 b[3][WN];
+            const char* a_s = a_rd + aoff * 16;
+            // halo terms are fetched one at a time, smallest first; term ta pairs with the weight terms tb <= NT-1-ta
+            // (bf16x6: a_l b_h; a_m b_m, a_m b_h; a_h b_l, a_h b_m, a_h b_h.  f16x3: a_l b_h; a_h b_l, a_h b_h)
 #pragma unroll
-            for (int term = 0; term < 3; term++)
+            for (int ta = NT - 1; ta >= 0; ta--) {
+                vec8 a[WM];
 #pragma unroll
-                for (int j = 0; j < WN; j++) b[term][j] = *reinterpret_cast<const bf16x8*>(b_s + term * BPL + 32 * j * 16);
+                for (int i = 0; i < WM; i++) a[i] = *reinterpret_cast<const vec8*>(a_s + ta * APL + i * ROWSTEP * 16);
 #pragma unroll
-            for (int ta = 2; ta >= 0; ta--) {
-                bf16x8 a[WM];
-#pragma unroll
-                for (int i = 0; i < WM; i++) a[i] = *reinterpret_cast<const bf16x8*>(a_s + ta * APL + i * ROWSTEP * 16);
-                // a_l pairs with b_h; a_m with b_m, b_h; a_h with b_l, b_m, b_h
-#pragma unroll
-                for (int tb = 2 - ta; tb >= 0; tb--)
+                for (int tb = NT - 1 - ta; tb >= 0; tb--)
 #pragma unroll
                     for (int i = 0; i < WM; i++)
 #pragma unroll
                         for (int j = 0; j < WN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[tb][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = F::mfma(a[i], b[t & 1][tb][j], acc[i][j]);
             }
-#ifndef RNR_ABLATE_EMU_NOBARRIER
-            __syncthreads();
+#ifdef RNR_EMU2_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);      // keep the taps apart: no hoisting of later taps' LDS reads
 #endif
         }
 #ifndef RNR_ABLATE_EMU_NOHALO
-        if (next_chunk) {       // every wave is past the last tap's reads: swap the next halo in
+        if (next_chunk && NGROUPS == TAPS) {        // the slice loaded during the last tap
 #pragma unroll
-            for (int j = 0; j < APT; j++)
-                if (tid + CTHREADS * j < ASLOTS) store_a(csn, av_all[j], j);
-            __syncthreads();
+            for (int u = 0; u < SPT; u++) {
+                const int j = (TAPS - 1) * SPT + u;
+                if (j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[(TAPS - 1) & 1][u], j, a_wr);
+            }
         }
 #endif
+        if (TAPS & 1) {
+#pragma unroll
+            for (int term = 0; term < NT; term++)
+#pragma unroll
+                for (int j = 0; j < WN; j++) b[0][term][j] = b[1][term][j];
+        }
+        __syncthreads();        // next halo complete and visible; everybody is done reading the current one
     }
 
     // ---- epilogue (identical to conv_halo_kernel: same accumulator layout) ----
+    if (FMT == 1) {         // undo the power-of-two weight scale (exact)
+        const float winv = *reinterpret_cast<const float*>(P.weight_emu);
+#pragma unroll
+        for (int i = 0; i < WM; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) acc[i][j][g] *= winv;
+    }
     float* out = P.out + (size_t)split * P.slab_stride;
 #pragma unroll
     for (int i = 0; i < WM; i++) {
@@ -1015,18 +1083,18 @@ conv_halo_emu_kernel(const ConvParams P) {
     }
 }
 
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
-    constexpr int TH = WAVES_M * WM, BN = WAVES_N * WN * 32;
+    constexpr int TH = WAVES_M * WM;
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds = (size_t)(96 * HP + 2 * 96 * ((BN + 63) / 64 * 64));
+    constexpr size_t lds = (size_t)(2 * EmuFmt<FMT>::NT * 32 * HP);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<KIND, WAVES_M, WAVES_N, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo_emu_kernel<KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
+    hipLaunchKernelGGL((conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
 }
 
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
@@ -1203,22 +1271,49 @@ pack_weight_kernel(rnr_conv_desc d, const float* __restrict__ w, float* __restri
     packed[(chunk * 4 + (2 * (k & 1) + (k >> 3))) * ((long)wstride * 4) + (long)co * 4 + ((k >> 1) & 3)] = v;
 }
 
-// bf16x6 image: [par][tap][chunk][3 terms][2 k-halves][wstride][8 bf16]  (conv_halo_emu_kernel)
+// max |w| over the PyTorch weight tensor, as the bit pattern of a non-negative float (orders like an unsigned)
+__global__ void __launch_bounds__(256) weight_amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ amax_bits) {
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = fabsf(w[i]);
+        if (v == v && v < __builtin_inff()) m = max(m, __builtin_bit_cast(unsigned, v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits, m);
+}
+
+// emulation image: 64-byte header, then [par][tap][chunk][NT terms][2 k-halves][wstride][8 x 16 bit]  (conv_halo_emu_kernel).
+// FMT 1 (f16x3): weights are multiplied by 2^k, k = 12 - floor(log2 max|w|), before the split; header[0] = 2^-k.
+template <int FMT>
 __global__ void __launch_bounds__(256)
-pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, unsigned short* __restrict__ packed, long total) {
+pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __restrict__ image, long total) {
+    constexpr int NT = EmuFmt<FMT>::NT;
+    float* header = reinterpret_cast<float*>(image);
+    unsigned short* packed = reinterpret_cast<unsigned short*>(image + EMU_HEADER_BYTES);
+    float wscale = 1.0f;
+    int kexp = 0;
+    if (FMT == 1) {
+        const float amax = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(image)[2]);
+        if (amax > 0.0f) {
+            kexp = 12 - ilogbf(amax);
+            kexp = min(max(kexp, -100), 100);
+        }
+        wscale = ldexpf(1.0f, kexp);
+    }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { header[0] = ldexpf(1.0f, -kexp); header[1] = (float)kexp; }
     if (i >= total) return;
     int par, tp, c, co, taps, ctot, wstride;
     gemm_weight_index(d, i, par, tp, c, co, taps, ctot, wstride);
-    const float v = gemm_weight(d, w, par, tp, c, co);
-    unsigned h, m, l;
-    split_bf16x3(v, 0.0f, h, m, l);
-    const unsigned term[3] = {h & 0xffffu, m & 0xffffu, l & 0xffffu};
+    const float v = gemm_weight(d, w, par, tp, c, co) * wscale;
+    unsigned term[NT];
+    EmuFmt<FMT>::split(v, 0.0f, term);
     const int k = c & 15;
     const long chunk = ((long)(par * taps + tp) * (ctot / 16) + (c >> 4));
 #pragma unroll
-    for (int t = 0; t < 3; t++)
-        packed[(((chunk * 3 + t) * 2 + (k >> 3)) * (long)wstride + co) * 8 + (k & 7)] = (unsigned short)term[t];
+    for (int t = 0; t < NT; t++)
+        packed[(((chunk * NT + t) * 2 + (k >> 3)) * (long)wstride + co) * 8 + (k & 7)] = (unsigned short)(term[t] & 0xffffu);
 }
 
 // mask[tile] = any(alpha > 0) over the 32 x th output pixels of the tile (tile order = the halo kernels' mt index)
@@ -1267,20 +1362,20 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
     }
     // bf16x6 emulation: 256 x 128 tiles (32 x 8 pixels, two waves per SIMD) halve the weight traffic and barriers per MFMA
-    if ((d->flags & RNR_CONV_F32_EMU_BF16X6) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
+    if ((d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
         p->Ho % 8 == 0) {
         p->bm = 256;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
     // exact-fp32 kernels: 256 x 128 tiles (two waves per SIMD, half the weight traffic and barriers per MFMA) once there
     // are enough of them to fill the 256 CUs twice over; below that the 128 x 128 tiles keep more CUs busy
-    if (!(d->flags & RNR_CONV_F32_EMU_BF16X6) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
+    if (!(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
         p->Ho % 8 == 0 && (long)(p->M / 256) * p->ntiles * p->par >= RNR_NATIVE_BIG_MIN) {
         p->bm = 256;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
     // ... and 64 x 128 tiles (32 x 2 pixels) for the 4x4-s2 convolution, whose halo is 5x the tile
-    if ((d->flags & RNR_CONV_F32_EMU_BF16X6) && d->kind == RNR_CONV4x4S2_REFLECT && p->cfg == 2 && p->Wo % 32 == 0 &&
+    if ((d->flags & RNR_CONV_F32_EMU_ANY) && d->kind == RNR_CONV4x4S2_REFLECT && p->cfg == 2 && p->Wo % 32 == 0 &&
         p->Ho % 2 == 0) {
         p->bm = 64;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
@@ -1309,6 +1404,15 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     return 0;
 }
 
+template <int FMT, int KIND>
+static void launch_halo_emu(const ConvPlan& pl, const dim3 grid, const ConvParams& P, hipStream_t st) {
+    if (KIND == 1) launch_halo_emu_cfg<FMT, 1, 2, 2, 1, 2>(grid, P, st);        // 64 x 128 (make_plan forces the 128-column config)
+    else if (pl.cfg == 0) launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 4, 1, 2, 2>(grid, P, st);         // 256 x 64
+    else if (pl.cfg == 1) launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 4, 1, 2, 3>(grid, P, st);         // 256 x 96 (Cout 78)
+    else if (pl.bm == 256) launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 2, 2, 4, 2>(grid, P, st);        // 256 x 128
+    else launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 2, 2, 2, 2>(grid, P, st);                          // 128 x 128
+}
+
 template <int KIND>
 static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
     const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
@@ -1335,8 +1439,9 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
                 "%s: c_in1 %d / pad %d", who, d->c_in1, d->c_in1_pad);
     RNR_REQUIRE(d->c_out > 0 && d->c_out_pad >= d->c_out && d->c_out_pad % BK == 0,
                 "%s: c_out %d / pad %d", who, d->c_out, d->c_out_pad);
-    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_BF16X6)) == 0, "%s: unknown flags 0x%x", who,
+    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_ANY)) == 0, "%s: unknown flags 0x%x", who,
                 d->flags);
+    RNR_REQUIRE((d->flags & RNR_CONV_F32_EMU_ANY) != RNR_CONV_F32_EMU_ANY, "%s: choose ONE emulation format", who);
     return 0;
 }
 
@@ -1352,8 +1457,10 @@ static size_t packed_f32_floats(const rnr_conv_desc* d) {
 extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
     if (!d) return 0;
     const size_t f32 = packed_f32_floats(d);
-    // bf16x6 image behind the fp32 image: 3 bf16 terms = 6 bytes per weight
-    return (d->flags & RNR_CONV_F32_EMU_BF16X6) ? f32 + (f32 * 6 + 3) / 4 : f32;
+    // emulation image behind the fp32 image: 64-byte header + 3 bf16 terms (6 bytes) or 2 fp16 terms (4 bytes) per weight
+    if (d->flags & RNR_CONV_F32_EMU_BF16X6) return f32 + EMU_HEADER_BYTES / 4 + (f32 * 6 + 3) / 4;
+    if (d->flags & RNR_CONV_F32_EMU_F16X3) return f32 + EMU_HEADER_BYTES / 4 + f32;
+    return f32;
 }
 
 extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream) {
@@ -1363,9 +1470,18 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        *d, weight, packed, total);
     if (int e = check_launch("pack_weight_kernel")) return e;
-    if (d->flags & RNR_CONV_F32_EMU_BF16X6) {
-        hipLaunchKernelGGL(pack_weight_emu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                           *d, weight, reinterpret_cast<unsigned short*>(packed + total), total);
+    if (d->flags & RNR_CONV_F32_EMU_ANY) {
+        char* image = reinterpret_cast<char*>(packed + total);
+        RNR_HIP(hipMemsetAsync(image, 0, EMU_HEADER_BYTES, as_stream(stream)));
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (d->flags & RNR_CONV_F32_EMU_F16X3) {
+            const long nw = (long)(d->c_in0 + d->c_in1) * d->c_out * (d->kind == RNR_CONV3x3_REFLECT ? 9 : 16);
+            hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)std::min<long>((nw + 255) / 256, 1024)), dim3(256), 0,
+                               as_stream(stream), weight, nw, reinterpret_cast<unsigned*>(image) + 2);
+            hipLaunchKernelGGL(pack_weight_emu_kernel<1>, grid, dim3(256), 0, as_stream(stream), *d, weight, image, total);
+        } else {
+            hipLaunchKernelGGL(pack_weight_emu_kernel<0>, grid, dim3(256), 0, as_stream(stream), *d, weight, image, total);
+        }
         return check_launch("pack_weight_emu_kernel");
     }
     return 0;
@@ -1456,24 +1572,15 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.out = out_raw;
         P.slab_stride = 0;
     }
-    // bf16x6 emulation: 3x3 and transposed convolutions on the halo plan with 64- or 128-column tiles
-    const bool emu = (d->flags & RNR_CONV_F32_EMU_BF16X6) && pl.halo && (d->kind != RNR_CONV4x4S2_REFLECT || pl.bm == 64);
+    // fp32 emulation on the 16-bit matrix cores: every convolution on the halo plan
+    const bool emu = (d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && (d->kind != RNR_CONV4x4S2_REFLECT || pl.bm == 64);
     if (emu) {
         P.weight_emu = weight_packed + packed_f32_floats(d);
         const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
-        if (d->kind == RNR_CONV4x4S2_REFLECT) {
-            launch_halo_emu_cfg<1, 2, 2, 1, 2>(grid, P, st);        // 64 x 128 (make_plan forces the 128-column config)
-        } else if (d->kind == RNR_CONV3x3_REFLECT) {
-            if (pl.cfg == 0) launch_halo_emu_cfg<0, 4, 1, 2, 2>(grid, P, st);
-            else if (pl.cfg == 1) launch_halo_emu_cfg<0, 4, 1, 2, 3>(grid, P, st);      // 256 x 96 (Cout 78)
-            else if (pl.bm == 256) launch_halo_emu_cfg<0, 2, 2, 4, 2>(grid, P, st);
-            else launch_halo_emu_cfg<0, 2, 2, 2, 2>(grid, P, st);
-        } else {
-            if (pl.cfg == 0) launch_halo_emu_cfg<2, 4, 1, 2, 2>(grid, P, st);
-            else if (pl.cfg == 1) launch_halo_emu_cfg<2, 4, 1, 2, 3>(grid, P, st);
-            else if (pl.bm == 256) launch_halo_emu_cfg<2, 2, 2, 4, 2>(grid, P, st);
-            else launch_halo_emu_cfg<2, 2, 2, 2, 2>(grid, P, st);
-        }
+        const bool f16 = (d->flags & RNR_CONV_F32_EMU_F16X3) != 0;
+        if (d->kind == RNR_CONV4x4S2_REFLECT) { if (f16) launch_halo_emu<1, 1>(pl, grid, P, st); else launch_halo_emu<0, 1>(pl, grid, P, st); }
+        else if (d->kind == RNR_CONV3x3_REFLECT) { if (f16) launch_halo_emu<1, 0>(pl, grid, P, st); else launch_halo_emu<0, 0>(pl, grid, P, st); }
+        else { if (f16) launch_halo_emu<1, 2>(pl, grid, P, st); else launch_halo_emu<0, 2>(pl, grid, P, st); }
     }
     else if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
     else if (pl.halo && d->kind == RNR_CONV4x4S2_REFLECT) launch_halo<1>(pl, P, st);

@@ -47,6 +47,8 @@ class RnrConvDesc(ctypes.Structure):
 ACT_NONE, ACT_LRELU02, ACT_RELU = 0, 1, 2
 CONV_STATS_PREZEROED = 1
 CONV_F32_EMU_BF16X6 = 2
+CONV_F32_EMU_F16X3 = 4
+EMU_FLAGS = {'f32': 0, 'bf16x6': CONV_F32_EMU_BF16X6, 'f16x3': CONV_F32_EMU_F16X3}
 CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2 = 0, 1, 2
 
 P = ctypes.POINTER

@@ -42,13 +42,14 @@ class UNetPlan:
         with update_running_stats the running_mean / running_var tensors of the state-dict are updated in place
         (momentum 0.1, unbiased variance) like torch does.
         'running': eval-mode BatchNorm from the running_mean / running_var buffers of the state-dict.
-        precision 'f32': exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  'bf16x6': fp32 emulated on the bf16 matrix cores —
-        operands split exactly into three bf16 terms, six partial products accumulated in fp32; error of the order of
-        fp32's own rounding, fewer MFMA cycles (include/rnr_hip.h, RNR_CONV_F32_EMU_BF16X6).
+        precision 'f32': exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  'bf16x6' / 'f16x3': fp32 emulated on the 16-bit matrix
+        cores — operands split into three bf16 terms (exactly; six partial products) or two fp16 terms (22 significand
+        bits; three partial products), accumulated in fp32; error of the order of fp32's own rounding, 2.7x / 5.3x fewer
+        MFMA cycles (include/rnr_hip.h, RNR_CONV_F32_EMU_BF16X6 / RNR_CONV_F32_EMU_F16X3).
         share_weights_with: another UNetPlan of the same network whose packed weights / BN parameters are reused
         (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
-        if precision not in ('f32', 'bf16x6'):
-            raise ValueError("precision must be 'f32' or 'bf16x6'")
+        if precision not in _lib.EMU_FLAGS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.EMU_FLAGS))
         if bn_mode not in ('batch', 'batch_all', 'running'):
             raise ValueError("bn_mode must be 'batch', 'batch_all' or 'running'")
         self.bn_mode = bn_mode
@@ -73,8 +74,7 @@ class UNetPlan:
             s0 = srcs[0]
             s1 = srcs[1] if len(srcs) > 1 else None
             desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
-            if precision == 'bf16x6':
-                desc.flags |= _lib.CONV_F32_EMU_BF16X6
+            desc.flags |= _lib.EMU_FLAGS[precision]
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
             else:

@@ -65,7 +65,7 @@ def _bench_scene():
             'sh_coeff': torch.from_numpy(scene.synthetic_sh_coeff(2, 10, 1))}
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16x6', 'f16x3'])
 def test_frame512_nf64_vs_oracle(precision):
     """Parity AT THE BENCHMARKED SIZE (test_rnr.py:265-377): 65 536 faces, C = 24, nf0 = 64, 512^2.
       * face_index_map / alpha EQUAL to the oracle on the same projected vertices (bit-exact integer bar);
@@ -192,9 +192,10 @@ def test_stream_lanes_match_single_stream():
     assert (call(lanes, 5) - first).abs().max() < 2e-5
 
 
-def test_bf16x6_emulation_frame():
-    """precision='bf16x6' (fp32 emulated on the bf16 matrix cores): the frame is as close to the oracle as the exact-fp32
-    frame is, and the two differ by float-rounding noise only."""
+@pytest.mark.parametrize('fmt', ['bf16x6', 'f16x3'])
+def test_emulation_frame(fmt):
+    """precision='bf16x6' / 'f16x3' (fp32 emulated on the 16-bit matrix cores): the frame is as close to the oracle as the
+    exact-fp32 frame is, and the two differ by float-rounding noise only."""
     from oracle import rnr_oracle as orc
     from rnr_amd import scene, testing
     from rnr_amd.pipeline import RNRPipeline
@@ -204,7 +205,7 @@ def test_bf16x6_emulation_frame():
     views = {k: T(v) for k, v in scene.spiral_views(256, [40, 400]).items()}
     dv = {k: v.to(DEV) for k, v in views.items()}
     f32 = mk('f32').render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv']).cpu()
-    emu = mk('bf16x6').render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv']).cpu()
+    emu = mk(fmt).render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv']).cpu()
     mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
     ref = orc.render_frame(mesh_t, views, 256, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'], sc['pivots_diff'])
     p32, pemu = orc.psnr(f32, ref['image']), orc.psnr(emu, ref['image'])

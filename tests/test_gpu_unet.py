@@ -144,10 +144,14 @@ EMU_CASES = [
 ]
 
 
+EMU_FORMATS = ['bf16x6', 'f16x3']
+
+
+@pytest.mark.parametrize('fmt', EMU_FORMATS)
 @pytest.mark.parametrize('kind,N,H,W,cins,c_out', EMU_CASES)
-def test_conv_f32_emulation_bf16x6(kind, N, H, W, cins, c_out):
-    """RNR_CONV_F32_EMU_BF16X6: the bf16x6 split on the bf16 matrix cores must be as close to a float64 convolution as
-    the exact-fp32 MFMA path is (its error is fp32 accumulation rounding, not the split)."""
+def test_conv_f32_emulation(kind, N, H, W, cins, c_out, fmt):
+    """RNR_CONV_F32_EMU_BF16X6 / _F16X3: fp32 emulated on the 16-bit matrix cores must be as close to a float64
+    convolution as the exact-fp32 MFMA path is (its error is fp32 accumulation rounding, not the operand split)."""
     from rnr_amd import _lib
     g = torch.Generator().manual_seed(7 + kind + H + c_out)
     srcs = []
@@ -161,7 +165,7 @@ def test_conv_f32_emulation_bf16x6(kind, N, H, W, cins, c_out):
     w = (torch.randn(cin, c_out, 4, 4, generator=g) if kind == 2 else torch.randn(c_out, cin, k, k, generator=g)) / (cin * k * k) ** 0.5
     ref = ref_conv(kind, srcs, w).permute(0, 2, 3, 1)
     f32, st32 = run_conv(kind, srcs, w, c_out, N, H, W)
-    emu, stemu = run_conv(kind, srcs, w, c_out, N, H, W, flags=_lib.CONV_F32_EMU_BF16X6)
+    emu, stemu = run_conv(kind, srcs, w, c_out, N, H, W, flags=_lib.EMU_FLAGS[fmt])
     e32 = (f32[..., :c_out].double() - ref).abs()
     eemu = (emu[..., :c_out].double() - ref).abs()
     scale = float(ref.abs().max())
@@ -174,7 +178,26 @@ def test_conv_f32_emulation_bf16x6(kind, N, H, W, cins, c_out):
     assert torch.allclose(stemu[:, :c_out, 1], st32[:, :c_out, 1], rtol=1e-4)
 
 
-def test_emulation_halo_swap_stress():
+@pytest.mark.parametrize('wmag', [1e-6, 3e-2, 40.0, 3e4])
+def test_f16x3_weight_scale_invariance(wmag):
+    """f16x3 pre-scales the weights by a per-layer power of two so that their fp16 residual terms stay normal: the
+    relative error vs float64 must not depend on the magnitude of the weights (1e-6 ... 3e4, beyond fp16's range)."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C, c_out = 1, 32, 32, 64, 64
+    srcs = [(torch.randn(N, C, H, W, generator=g), None, None, 1)]
+    w = torch.randn(c_out, C, 3, 3, generator=g) / (C * 9) ** 0.5 * wmag
+    ref = ref_conv(0, srcs, w).permute(0, 2, 3, 1)
+    f32, _ = run_conv(0, srcs, w, c_out, N, H, W)
+    emu, _ = run_conv(0, srcs, w, c_out, N, H, W, flags=_lib.CONV_F32_EMU_F16X3)
+    rel = lambda x: float(((x[..., :c_out].double() - ref).pow(2).mean().sqrt()) / ref.pow(2).mean().sqrt())
+    assert torch.isfinite(emu).all()
+    assert rel(emu) <= 1.1 * rel(f32), (rel(emu), rel(f32))
+    assert rel(emu) < 2e-7
+
+
+@pytest.mark.parametrize('fmt', EMU_FORMATS)
+def test_emulation_halo_swap_stress(fmt):
     """Regression: at 512^2 the 256x96 bf16x6 kernel once produced sporadically corrupted 16-lane groups of its halo
     (duplicate stores of the slots past the halo).  Ten launches of the out-layer shape must all agree with fp32."""
     from rnr_amd import _lib
@@ -184,7 +207,7 @@ def test_emulation_halo_swap_stress():
     w = torch.randn(c_out, sum(cins), 3, 3, generator=g) / (sum(cins) * 9) ** 0.5
     nat, _ = run_conv(0, srcs, w, c_out, N, H, W)
     for rep in range(10):
-        emu, _ = run_conv(0, srcs, w, c_out, N, H, W, flags=_lib.CONV_F32_EMU_BF16X6)
+        emu, _ = run_conv(0, srcs, w, c_out, N, H, W, flags=_lib.EMU_FLAGS[fmt])
         assert (emu - nat).abs().max() < 1e-4, rep
 
 
