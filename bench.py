@@ -135,9 +135,9 @@ def cpu_baseline(sc, args, view_id, hip_image, emu_image=None, budget_s=30.0):
     if hip_image is not None:
         parity = {'psnr_db_vs_oracle': orc.psnr(hip_image.cpu(), ref['image']),
                   'max_abs_err': float((hip_image.cpu() - ref['image']).abs().max())}
-        if emu_image is not None:
-            parity['bf16x6_psnr_db_vs_oracle'] = orc.psnr(emu_image.cpu(), ref['image'])
-            parity['bf16x6_max_abs_err'] = float((emu_image.cpu() - ref['image']).abs().max())
+        for prec, img in (emu_image or {}).items():
+            parity[prec + '_psnr_db_vs_oracle'] = orc.psnr(img.cpu(), ref['image'])
+            parity[prec + '_max_abs_err'] = float((img.cpu() - ref['image']).abs().max())
     return out, parity
 
 
@@ -265,7 +265,6 @@ def main():
         gather_check = {'ok': int(bad.sum().item()) == 0, 'ranks_with_mismatch': int(bad[0].item()),
                         'gathered_shape': list(gather.latest.shape), 'backend': dist.get_backend()}
     last_frame = img[V - 1:V].clone()       # the frame buffers are reused by the extra renders below
-    emu_last = None
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -280,6 +279,8 @@ def main():
     flops_step = (pipe.unet.flops_per_view - skipped * out_flops_view) * V
     n_conv = len(pipe.unet.steps)
     achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
+    peak_tf = {'f32': PEAK_F32_MFMA_TFLOPS, 'bf16x6': 2500.0 / 6, 'f16x3': 2500.0 / 3}[args.precision]
+    dtype = {'f32': 'f32', 'bf16x6': 'f32 emulated on bf16 MFMA (bf16x6)', 'f16x3': 'f32 emulated on f16 MFMA (f16x3)'}[args.precision]
 
     if rank == 0:
         traffic, traffic_info = pmc_traffic_per_step(args)
@@ -288,16 +289,16 @@ def main():
                       % (args.img_size, args.img_size),
             'value': args.steps * world * V / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2] in %d-view batches (the reference renders 1 view per call; that mode is '
                                    'reported as single_view_mode): test_rnr.py spiral_step720 views, %dx%d, full HIP RenderingNet '
                                    '(f32 MFMA convs + SH relight), UV-sphere 65536 faces, neural texture 512^2 x %d ch x 4 '
                                    'levels, U-Net %d->%d nf0=%d' % (V, args.img_size, args.img_size, args.tex_ch, sc['c_in'],
                                                                    3 * sc['n_rays'], args.nf0),
                        'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel / conv_mfma_kernel (%d conv launches/step; HIP events bracket the U-Net stage incl. bn_finalize + split-K reduce)' % n_conv,
-                         'achieved': achieved_tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'kernel': '%s / conv_mfma_kernel (%d conv launches/step; HIP events bracket the U-Net stage incl. bn_finalize + split-K reduce)' % ('conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
+                         'achieved': achieved_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
+                         'frac': achieved_tf / peak_tf, 'traffic': traffic,
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
                          **traffic_info,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
@@ -370,35 +371,70 @@ def main():
                                                        'ms_per_step': dt2 / args.steps * 1e3,
                                                        'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
                 del pipe2
+        emu_last = {}
         if extras and world == 1 and args.precision == 'f32':
-            # fp32 emulated on the bf16 matrix cores (RNR_CONV_F32_EMU_BF16X6), same tuned configuration
-            pipe3 = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
-                                sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
-                                sh_lmax=10, skip_background_tiles=False, precision='bf16x6')
+            # fp32 emulated on the 16-bit matrix cores (RNR_CONV_F32_EMU_BF16X6 / _F16X3): opt-in configurations of the same
+            # pipeline, each with its OWN roofline block — the peak is the dense 16-bit MFMA rate divided by the partial
+            # products per multiply-add (2.5 PFLOP/s / 6 resp. / 3), the achieved figure the same algorithmic fp32 FLOPs
             lo = (args.warmup + args.steps - 1) * V
             sl = slice(lo, lo + V)
-            emu_img = pipe3.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
-            native = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
-            diff = float((emu_img - native).abs().max())
-            emu_last = emu_img[V - 1:V].clone()
-            dt3 = timed(pipe3)
-            res['with_f32_emulation_bf16x6'] = {
-                'frames_per_s': args.steps * V / dt3, 'ms_per_step': dt3 / args.steps * 1e3,
-                'max_abs_diff_vs_f32_mfma_frames': diff,
-                'note': 'RNRPipeline(precision="bf16x6"): every conv operand split exactly into 3 bf16 terms, 6 partial '
-                        'products accumulated in fp32 on v_mfma_f32_32x32x16_bf16; full compute on every pixel, one stream; '
-                        'not the headline value'}
-            del pipe3
-            if True:
-                pipe4 = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
-                                    sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
-                                    sh_lmax=10, skip_background_tiles=True, streams=1, precision='bf16x6')
-                dt4 = timed(pipe4)
-                res['with_all_opt_in_fast_paths'] = {
-                    'frames_per_s': args.steps * V / dt4, 'ms_per_step': dt4 / args.steps * 1e3,
-                    'note': 'RNRPipeline(precision="bf16x6", skip_background_tiles=True), one stream (two streams do not help the '
-                            'emulation kernels); not the headline value'}
-                del pipe4
+            native = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl]).clone()
+            for prec, products, what in [
+                    ('bf16x6', 6, 'every conv operand split exactly into 3 bf16 terms, 6 partial products accumulated in fp32 on '
+                                  'v_mfma_f32_32x32x16_bf16'),
+                    ('f16x3', 3, 'every conv operand split into 2 fp16 terms (22 significand bits, weights pre-scaled per layer by '
+                                 'a power of two), 3 partial products accumulated in fp32 on v_mfma_f32_32x32x16_f16; error vs '
+                                 'float64 below the exact-fp32 kernel on 20 of 22 layer shapes (profiles/r02_emu_layer_table.md)')]:
+                pe = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
+                                 sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
+                                 sh_lmax=10, skip_background_tiles=False, precision=prec)
+                emu_img = pe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+                diff = float((emu_img - native).abs().max())
+                emu_last[prec] = emu_img[V - 1:V].clone()
+                # U-Net stage by HIP events on the launch stream, as for the headline
+                eve = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+                fwd = pe.unet.forward
+
+                def timed_fwd(net_in, n_views=None, consumer_alpha=None, _i=[0], _e=eve, _f=fwd):
+                    k = _i[0]
+                    if k < len(_e) // 2:
+                        _e[2 * k].record()
+                    r = _f(net_in, n_views, consumer_alpha)
+                    if k < len(_e) // 2:
+                        _e[2 * k + 1].record()
+                    _i[0] += 1
+                    return r
+                for s0 in range(2):     # warm-up outside the hooked region
+                    pe.render(poses['proj'][:V], poses['pose'][:V], poses['proj_inv'][:V], poses['R_inv'][:V])
+                pe.unet.forward = timed_fwd
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for s0 in range(args.warmup, args.warmup + args.steps):
+                    lo2 = (s0 % (args.steps + args.warmup)) * V
+                    sl2 = slice(lo2, lo2 + V)
+                    pe.render(poses['proj'][sl2], poses['pose'][sl2], poses['proj_inv'][sl2], poses['R_inv'][sl2])
+                torch.cuda.synchronize()
+                dte = time.perf_counter() - t1
+                pe.unet.forward = fwd
+                ums = float(np.mean([eve[2 * i].elapsed_time(eve[2 * i + 1]) for i in range(args.steps)]))
+                peak = 2500.0 / products
+                tf = pe.unet.flops_per_view * V / (ums * 1e-3) / 1e12
+                res['with_f32_emulation_' + prec] = {
+                    'frames_per_s': args.steps * V / dte, 'ms_per_step': dte / args.steps * 1e3,
+                    'max_abs_diff_vs_f32_mfma_frames': diff,
+                    'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_emu_kernel<%s> (U-Net stage, HIP events)' % prec,
+                                 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the exact '
+                                 'convolution; peak = 2500 dense 16-bit MFMA TFLOP/s / %d partial products)' % products,
+                                 'frac': tf / peak, 'stage_ms_per_step': ums},
+                    'note': 'RNRPipeline(precision="%s"): %s; full compute on every pixel, one stream; not the headline value'
+                            % (prec, what)}
+                if prec == 'f16x3':
+                    pe.skip_background_tiles = True
+                    dt4 = timed(pe)
+                    res['with_all_opt_in_fast_paths'] = {
+                        'frames_per_s': args.steps * V / dt4, 'ms_per_step': dt4 / args.steps * 1e3,
+                        'note': 'RNRPipeline(precision="f16x3", skip_background_tiles=True), one stream; not the headline value'}
+                del pe
         if world == 1 and V > 1 and extras:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
