@@ -310,6 +310,7 @@ def main():
         if gather_check is not None:
             res['gather_check'] = gather_check
         extras = not args.main_loop_only
+        fast = os.environ.get('RNR_BENCH_FAST') == '1'      # scripts/stage.sh: headline loop + per-stage figures only
         # per-stage HIP events (5 extra steps outside the timed region): the non-conv stages against the HBM roofline
         P_px = args.img_size * args.img_size
         m = sc['mesh']
@@ -351,7 +352,7 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t1
 
-        if extras and world == 1 and not args.tile_skip and out_tiles_per_step:
+        if extras and not fast and world == 1 and not args.tile_skip and out_tiles_per_step:
             # product-tuned configuration of RNRPipeline, reported beside the headline (frames are bit-identical /
             # equal to 1e-6): out-layer pixel tiles without a foreground pixel are not computed, and the batch is split
             # over two HIP streams so that kernel tails overlap
@@ -372,7 +373,7 @@ def main():
                                                        'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
                 del pipe2
         emu_last = {}
-        if extras and world == 1 and args.precision == 'f32':
+        if extras and not fast and world == 1 and args.precision == 'f32':
             # fp32 emulated on the 16-bit matrix cores (RNR_CONV_F32_EMU_BF16X6 / _F16X3): opt-in configurations of the same
             # pipeline, each with its OWN roofline block — the peak is the dense 16-bit MFMA rate divided by the partial
             # products per multiply-add (2.5 PFLOP/s / 6 resp. / 3), the achieved figure the same algorithmic fp32 FLOPs
@@ -435,7 +436,7 @@ def main():
                         'frames_per_s': args.steps * V / dt4, 'ms_per_step': dt4 / args.steps * 1e3,
                         'note': 'RNRPipeline(precision="f16x3", skip_background_tiles=True), one stream; not the headline value'}
                 del pe
-        if world == 1 and V > 1 and extras:
+        if world == 1 and V > 1 and extras and not fast:
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
             def one(s):

@@ -236,8 +236,12 @@ shade_inputs_kernel(const ShadeParams P) {
     __syncthreads();
 
     // ---- phase 1: (pixel, ray) items: reflect / diffuse directions (network.py:455-465) ----
+    // lanes run over the rays of a pixel first: a wave stores 3-float records at a stride of 3 floats (3 is coprime with
+    // the 32 banks: conflict-free), and reads the geometry record of only ~3 pixels (LDS broadcast).  With the pixel
+    // fastest every lane of a wave hit one of two banks (row stride 112 floats = 16 mod 32): 16-way conflicts,
+    // 72 M conflict cycles per dispatch in the round-1 profile.
     for (int i = tid; i < SH_PIX * n_rays; i += SH_THREADS) {
-        const int p = i % SH_PIX, r = i / SH_PIX;
+        const int p = i / n_rays, r = i - p * n_rays;
         const float* g = geo + p * GEO;
         const float3 tt = f3(g[0], g[1], g[2]), bt = f3(g[3], g[4], g[5]), nm = f3(g[6], g[7], g[8]);
         const float a = g[14];
@@ -306,7 +310,8 @@ shade_inputs_kernel(const ShadeParams P) {
             if (c0 + 3 >= 0 && c0 + 3 < 9) acc.w *= sh[c0 + 3];
         }
         float* tp = tile + p * cp + c_geo + 6 + 4 * q;
-        tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w;
+        if (((c_geo + 6) & 3) == 0) *reinterpret_cast<float4*>(tp) = acc;     // one ds_write_b128 (rows are 16-byte aligned)
+        else { tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w; }
     }
     __syncthreads();
 
@@ -387,11 +392,22 @@ struct RayParams {
     long npix; int hw;
 };
 
+// sum over each aligned group of 16 lanes, result in every lane of the group: four DPP adds on the VALU (quad_perm
+// swaps 1 and 2 apart, row_half_mirror and row_mirror fold 8 and 16 lanes) instead of four ds_bpermute round trips
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int y;
+    if (ctrl_sel == 0) y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if (ctrl_sel == 1) y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if (ctrl_sel == 2) y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    else y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);                     // row_mirror
+    return v + __builtin_bit_cast(float, y);
+}
 __device__ __forceinline__ float seg16_sum(float v) {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+    v = dpp_add(v, 0);
+    v = dpp_add(v, 1);
+    v = dpp_add(v, 2);
+    v = dpp_add(v, 3);
     return v;
 }
 
@@ -399,14 +415,20 @@ constexpr int RR_PIX = 4;     // pixels per lane: independent load chains in fli
 
 __global__ void __launch_bounds__(256)
 ray_render_kernel(const RayParams P) {
-    const long gl = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long grp = gl >> 5;                 // a 32-lane half-wave owns RR_PIX consecutive pixels
-    const int sub = (int)(gl & 31);
+    // a 32-lane half-wave owns RR_PIX consecutive pixels; a workgroup owns 8 * RR_PIX consecutive pixels, so every
+    // global address is a workgroup-uniform base (SGPR pair) plus a small 32-bit lane offset: no 64-bit VALU math
+    constexpr int PIX_PER_WG = 8 * RR_PIX;
+    const long wg_pix0 = (long)blockIdx.x * PIX_PER_WG;
+    const int sub = (int)(threadIdx.x & 31);
+    const int lp0 = (int)(threadIdx.x >> 5) * RR_PIX;       // first pixel of this half-wave inside the workgroup
     const bool is_diff = sub >= 16;
     const int rr = sub & 15;
     const bool ray_live = is_diff ? rr < P.n_diff : rr < P.n_spec;
     const int r = is_diff ? P.n_spec + rr : rr;
-    const long pix0 = grp * RR_PIX;
+    const long pix0 = wg_pix0 + lp0;
+    const float* wg_net_in = P.net_in + wg_pix0 * P.c_pad;
+    const float* wg_raw = P.unet_raw + wg_pix0 * P.c_out_pad;
+    const float* wg_alpha = P.alpha + wg_pix0;
     float dx[RR_PIX], dy[RR_PIX], dz[RR_PIX], al[RR_PIX], y0[RR_PIX], y1[RR_PIX], y2[RR_PIX];
     bool live[RR_PIX];
 #pragma unroll
@@ -415,11 +437,11 @@ ray_render_kernel(const RayParams P) {
         live[k] = ray_live && pix < P.npix;
         dx[k] = dy[k] = dz[k] = al[k] = y0[k] = y1[k] = y2[k] = 0.f;
         if (live[k]) {
-            const float* d = P.net_in + pix * P.c_pad + 3 * r;
-            const float* yr = P.unet_raw + pix * P.c_out_pad + 3 * r;
+            const float* d = wg_net_in + (unsigned)((lp0 + k) * P.c_pad + 3 * r);
+            const float* yr = wg_raw + (unsigned)((lp0 + k) * P.c_out_pad + 3 * r);
             dx[k] = d[0]; dy[k] = d[1]; dz[k] = d[2];
             y0[k] = yr[0]; y1[k] = yr[1]; y2[k] = yr[2];
-            al[k] = P.alpha[pix];
+            al[k] = wg_alpha[lp0 + k];
         }
     }
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -444,10 +466,10 @@ ray_render_kernel(const RayParams P) {
         c0[k] = c1[k] = c2[k] = 0.f;
         if (live[k]) {
             const Taps& t = tp[k];
-            const float* l00 = P.lp + ((size_t)t.y0 * P.lp_w + t.x0) * 3;
-            const float* l10 = P.lp + ((size_t)t.y1 * P.lp_w + t.x0) * 3;
-            const float* l01 = P.lp + ((size_t)t.y0 * P.lp_w + t.x1) * 3;
-            const float* l11 = P.lp + ((size_t)t.y1 * P.lp_w + t.x1) * 3;
+            const float* l00 = P.lp + (unsigned)((t.y0 * P.lp_w + t.x0) * 3);
+            const float* l10 = P.lp + (unsigned)((t.y1 * P.lp_w + t.x0) * 3);
+            const float* l01 = P.lp + (unsigned)((t.y0 * P.lp_w + t.x1) * 3);
+            const float* l11 = P.lp + (unsigned)((t.y1 * P.lp_w + t.x1) * 3);
             const float col0 = l00[0] * t.w00 + l10[0] * t.w10 + l01[0] * t.w01 + l11[0] * t.w11;
             const float col1 = l00[1] * t.w00 + l10[1] * t.w10 + l01[1] * t.w01 + l11[1] * t.w11;
             const float col2 = l00[2] * t.w00 + l10[2] * t.w10 + l01[2] * t.w01 + l11[2] * t.w11;
@@ -468,7 +490,7 @@ ray_render_kernel(const RayParams P) {
         const float d0 = __shfl_down(s0, 16, 64), d1 = __shfl_down(s1, 16, 64), d2 = __shfl_down(s2, 16, 64);
         const long pix = pix0 + k;
         if (sub == 0 && pix < P.npix) {
-            const float* ni = P.net_in + pix * P.c_pad + 3 * (P.n_spec + P.n_diff) + 6;
+            const float* ni = wg_net_in + (unsigned)((lp0 + k) * P.c_pad + 3 * (P.n_spec + P.n_diff) + 6);
             const long n = pix / P.hw, rem = pix % P.hw;
             const float o[3] = {s0, s1, s2}, dd[3] = {d0, d1, d2};
 #pragma unroll
