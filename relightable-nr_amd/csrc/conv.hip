@@ -365,8 +365,10 @@ conv_mfma_kernel(const ConvParams P) {
 //                           element (y+oy(ty), x+ox(tx))                                   4 taps
 // Versus the tap-by-tap gather of conv_mfma_kernel the L2->LDS traffic, the global-load / ds_write instruction count
 // and the prologue math of the A operand drop by taps*256/halo = 6.8x / 3.1x / 3.0x; the MFMA work is identical.
-// Pipeline step = one (chunk, tap): the next step's weights and a slice of the next chunk's halo are fetched to
-// registers before the step's MFMAs and stored to the alternate LDS buffers after them; one barrier per step.
+// Weights do not pass through LDS: a tap's B operand is 2*WN coalesced buffer loads per wave straight into the MFMA
+// operand registers, requested one tap ahead.  A slice of the next chunk's halo is fetched before a tap's MFMAs and
+// stored to the alternate LDS buffer after them; ONE barrier per 16-channel chunk (round 1 staged weight tiles by
+// LDS-DMA and needed a barrier per tap).
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
 __global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
@@ -392,15 +394,12 @@ conv_halo_kernel(const ConvParams P) {
     // An MFMA lane (x, h) needs channels k = 2s+h, s = 0..7, of ONE pixel / column: that is planes 2h and 2h+1 at
     // lane-consecutive float4s -> two conflict-free ds_read_b128 per operand row per tap, every address an immediate
     // offset from one per-lane base (the old [k][X] image took 16 ds_read_b32 and a VALU add per pair).
-    constexpr int ACH = 16 * HP, BCH = 16 * BN;            // floats per chunk image
-    constexpr int NPB = 4 * ((BN + 63) / 64);              // DMA pieces (<= 64 columns of one plane) per weight tile
-    constexpr int BPT = (NPB + 3) / 4;                     // pieces per wave
+    constexpr int ACH = 16 * HP;                           // floats per halo chunk image
     static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
     static_assert(BK == 16, "plane mapping assumes 16-channel chunks");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [ABUFS][ACH]
-    float* Bs = smem + ABUFS * ACH;         // [2][BCH]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -455,13 +454,17 @@ conv_halo_kernel(const ConvParams P) {
 
     // view base + channel offset are wave-uniform (SGPR pair); the per-lane part is a 32-bit element offset
     // (make_plan keeps H*W*C below 2^30), so a halo fetch is one global_load_dwordx4 v, voff, s[base] and one VALU mad.
-    struct ChunkSrc { const float* base; unsigned C; int act; float4 sc, sh; };
+    // (buffer loads: resource + scalar offset + one 32-bit lane offset; flat 64-bit addresses make the unrolled tap loop
+    // keep a strength-reduced pointer pair per (tap, plane) alive across the chunk loop — registers the kernel lacks)
+    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; float4 sc, sh; };
     auto chunk_src = [&](int c) {
         ChunkSrc cs;
         const int s = c < P.chunks0 ? 0 : 1;
         const int cc = (c - (s ? P.chunks0 : 0)) * BK;
         cs.C = (unsigned)P.src_c[s];
-        cs.base = P.src_data[s] + (size_t)n * P.H * P.W * cs.C + cc;
+        cs.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src_data[s] + (size_t)n * P.H * P.W * cs.C), 0,
+                                                    0x7fffffff, 0x27000);
+        cs.soff = (unsigned)cc * 4u;
         cs.act = P.src_act[s];
         cs.sc = make_float4(1.f, 1.f, 1.f, 1.f);
         cs.sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -470,8 +473,8 @@ conv_halo_kernel(const ConvParams P) {
         return cs;
     };
     auto load_a = [&](const ChunkSrc& cs, int j) {
-        const unsigned voff = spix[j] * cs.C + 4u * (unsigned)q;
-        return *reinterpret_cast<const float4*>(cs.base + voff);
+        const unsigned voff = (spix[j] * cs.C + 4u * (unsigned)q) * 4u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, (int)voff, (int)cs.soff, 0));
     };
     auto store_a = [&](const ChunkSrc& cs, float4 v, int j, int buf) {
         float x = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
@@ -483,34 +486,29 @@ conv_halo_kernel(const ConvParams P) {
         *reinterpret_cast<float2*>(a) = make_float2(x, z);                  // channels 4q, 4q+2   (h = 0 planes)
         *reinterpret_cast<float2*>(a + 2 * HP * 4) = make_float2(y, w);     // channels 4q+1, 4q+3 (h = 1 planes)
     };
-    // Weight tile of one (chunk, tap): the packed layout (pack_weight_kernel) already is the plane image, per chunk
-    // [4][wstride][4] floats, so a tile is 4 runs of BN float4 starting at column n0.  It goes global -> LDS by DMA
-    // (global_load_lds_dwordx4: no VGPRs, no ds_write; LDS image = wave-uniform base + lane*16 B) in pieces of <= 64
-    // columns.  The barrier that ends the step drains it (hipcc emits vmcnt(0) before s_barrier while an LDS-DMA is
-    // in flight).
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    constexpr int RUNS = (BN + 63) / 64;
-    unsigned bvoff[BPT];     // per-lane float offset of this wave's piece b inside a (chunk, tap) weight block
-    int blds[BPT];           // wave-uniform float offset of the piece inside a weight tile image
-    bool blive[BPT];         // lane takes part (pieces of 64 columns: all lanes; the 16-column tail: 16 lanes)
+    // Weights of one (chunk, tap): the packed layout (pack_weight_kernel) is the plane image [4 planes][wstride][4 floats]
+    // per chunk, and an MFMA lane (column, k parity h) needs exactly the float4s of planes 2h and 2h+1 at its column:
+    // lanes of a wave are consecutive columns, so a tap's B operand is 2*WN coalesced buffer_load_dwordx4 per wave
+    // straight into the operand registers, requested one tap ahead.  No LDS weight tile, no LDS-DMA, and therefore no
+    // barrier per tap: the only LDS hazard left is the halo swap (one barrier per chunk).
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.weight), 0, 0x7fffffff, 0x27000);
+    const unsigned tile_bytes = 64u * (unsigned)P.wstride;                  // one (chunk, tap) block: 16 channels x wstride floats
+    unsigned bvoff[2];
 #pragma unroll
-    for (int b = 0; b < BPT; b++) {
-        const int pc = wave_u + 4 * b;                      // piece = (plane, 64-column run), wave-uniform
-        const int g = pc / RUNS, run = pc - g * RUNS;
-        bvoff[b] = ((unsigned)g * (unsigned)P.wstride + (unsigned)(n0 + 64 * run + lane)) * 4u;
-        blds[b] = (g * BN + 64 * run) * 4;
-        blive[b] = pc < NPB && (BN % 64 == 0 || lane < BN - 64 * run);
-    }
-    auto dma_b = [&](int c, int t, int buf) {
-        const float* wt = P.weight + ((size_t)(par * TAPS + t) * nchunks + c) * (16 * (size_t)P.wstride);
+    for (int sg = 0; sg < 2; sg++)
+        bvoff[sg] = ((unsigned)(2 * h + sg) * (unsigned)P.wstride + (unsigned)(n0 + wn0 + l31)) * 16u;
+    const int g16 = (kq & 1) * 2 + (kq >> 1);
+    const unsigned bvoff16 = ((unsigned)g16 * (unsigned)P.wstride + (unsigned)(n0 + wn0 + WN * 32 + l15)) * 16u;
+    struct BRegs { floatx4 b[2][WN]; floatx4 b16; };
+    auto load_b = [&](BRegs& dst, int c, int t) {
+        const unsigned soff = (unsigned)((par * TAPS + t) * nchunks + c) * tile_bytes;      // wave-uniform
 #pragma unroll
-        for (int b = 0; b < BPT; b++) {
-            if ((NPB % 4 == 0 && BN % 64 == 0) || blive[b]) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + bvoff[b]),
-                                                 (__attribute__((address_space(3))) void*)(Bs + buf * BCH + blds[b]),
-                                                 16, 0, 0);
-            }
-        }
+        for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+                dst.b[sg][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(bvoff[sg] + 512u * j),
+                                                                                             (int)soff, 0));
+        if (R16) dst.b16 = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)bvoff16, (int)soff, 0));
     };
 
     floatx16 acc[WM][WN];
@@ -528,33 +526,27 @@ conv_halo_kernel(const ConvParams P) {
     // per-lane LDS bases (floats): plane pair of this lane's k parity, its pixel / column, the wave's rows
     const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
     const float* a_lane = As + ((2 * h) * HP + wrow + l31) * 4;
-    const float* b_lane = Bs + ((2 * h) * BN + wn0 + l31) * 4;
-    const int g16 = (kq & 1) * 2 + (kq >> 1);
     const float* a16_lane = As + (g16 * HP + wrow + l15) * 4;
-    const float* b16_lane = Bs + (g16 * BN + wn0 + WN * 32 + l15) * 4;
 
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
 #pragma unroll
         for (int j = 0; j < APT; j++)
             if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j, 0);
-        dma_b(c_begin, 0, 0);
     }
+    BRegs breg[2];
+    if (c_begin < c_end) load_b(breg[0], c_begin, 0);
     __syncthreads();
-    int step = 0;
     for (int c = c_begin; c < c_end; c++) {
         const int abuf = ABUFS == 2 ? ((c - c_begin) & 1) : 0;
         const bool next_chunk = c + 1 < c_end;
         ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
         float4 av_all[ABUFS == 1 ? APT : 1];
 #pragma unroll
-        for (int t = 0; t < TAPS; t++, step++) {
-            const bool more = next_chunk || t < TAPS - 1;
-#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_B)
-            if (more) {
-                if (t < TAPS - 1) dma_b(c, t + 1, (step + 1) & 1); else dma_b(c + 1, 0, (step + 1) & 1);
-            }
-#endif
+        for (int t = 0; t < TAPS; t++) {
+            // the next tap's (or the next chunk's first) weights are requested before this tap's MFMAs
+            if (t < TAPS - 1) load_b(breg[(t + 1) & 1], c, t + 1);
+            else if (next_chunk) load_b(breg[TAPS & 1], c + 1, 0);
             float4 av[APS];
 #pragma unroll
             for (int u = 0; u < APS; u++) {
@@ -575,24 +567,22 @@ conv_halo_kernel(const ConvParams P) {
             else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
             constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;      // halo pixels between consecutive output rows
             const float* a_s = a_lane + abuf * ACH + aoff * 4;
-            const float* b_s = b_lane + (step & 1) * BCH;
+            const BRegs& bt = breg[t & 1];
 #pragma unroll
             for (int sg = 0; sg < 2; sg++) {
-                floatx4 a4[WM], b4[WN];
+                floatx4 a4[WM];
 #pragma unroll
                 for (int i = 0; i < WM; i++) a4[i] = *reinterpret_cast<const floatx4*>(a_s + (sg * HP + i * ROWSTEP) * 4);
-#pragma unroll
-                for (int j = 0; j < WN; j++) b4[j] = *reinterpret_cast<const floatx4*>(b_s + (sg * BN + 32 * j) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; e++)
 #pragma unroll
                     for (int i = 0; i < WM; i++)
 #pragma unroll
                         for (int j = 0; j < WN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], b4[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], bt.b[sg][j][e], acc[i][j], 0, 0, 0);
             }
             if (R16) {      // 16-column remainder: lane (row/col = l&15, kq = l>>4) takes plane (kq&1)*2 + (kq>>1): 4 k per MFMA
-                const floatx4 bv = *reinterpret_cast<const floatx4*>(b16_lane + (step & 1) * BCH);
+                const floatx4 bv = bt.b16;
 #pragma unroll
                 for (int sb = 0; sb < 2 * WM; sb++) {
                     const floatx4 av16 = *reinterpret_cast<const floatx4*>(
@@ -611,14 +601,10 @@ conv_halo_kernel(const ConvParams P) {
                 }
             }
 #endif
-#ifdef RNR_ABLATE_RAWBAR
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#elif !defined(RNR_ABLATE_NOBARRIER)
-            __syncthreads();
-#endif
         }
-        if (ABUFS == 1 && next_chunk) {     // every wave is past the last tap's reads: swap the next halo in
+        if (TAPS & 1) breg[0] = breg[1];
+        __syncthreads();                    // everybody is done reading this chunk's halo; the next one (ABUFS == 2) is complete
+        if (ABUFS == 1 && next_chunk) {     // single LDS copy: swap the register-parked halo in
 #pragma unroll
             for (int j = 0; j < APT; j++)
                 if (tid + CTHREADS * j < ASLOTS) store_a(csn, av_all[j], j, 0);
@@ -1101,7 +1087,9 @@ template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM, BN = WAVES_N * (WN * 32 + R16 * 16);
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds = (size_t)((KIND == 1 ? 1 : 2) * BK * HP + 2 * BK * BN) * sizeof(float);
+    constexpr size_t lds_halo = (size_t)((KIND == 1 ? 1 : 2) * BK * HP) * sizeof(float);
+    constexpr size_t lds_red = (size_t)(WAVES_M * BN * 2) * sizeof(float);         // statistics reduction of the epilogue
+    constexpr size_t lds = lds_halo > lds_red ? lds_halo : lds_red;
     static bool attr_set = false;
     if (!attr_set) {    // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>),
