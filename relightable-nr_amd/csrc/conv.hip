@@ -796,9 +796,15 @@ conv_halo_emu_kernel(const ConvParams P) {
     static_assert(WAVES_M * WAVES_N == 4 && BK == 16, "four waves, 16-channel chunks");
     constexpr int TW = 32, TH = WAVES_M * WM;
     constexpr int BN = WAVES_N * WN * 32;
-    constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
-    constexpr int HWD = KIND == 1 ? 2 * TW + 2 : TW + 2;
-    constexpr int HHT = KIND == 1 ? 2 * TH + 2 : TH + 2;
+    // KIND 1 (4x4 stride 2) runs as FOUR stride-1 2x2-tap convolutions, one per input parity phase (py, px): input
+    // row 2y + ky - 1 = 2(y + ty) + py with (ky; ty, py) = (0; -1, 1), (1; 0, 0), (2; 0, 1), (3; 1, 0).  A K step is a
+    // (16-channel chunk, phase) pair whose halo is the (TH+1) x 33 pixels of THAT phase only (297 pixels for a 32 x 8
+    // tile, where the interleaved 66-wide halo of all 16 taps takes 1188): small enough to double-buffer 256-row tiles
+    // at two workgroups per CU, 4 taps between barriers.
+    constexpr int NPH = KIND == 1 ? 4 : 1;                    // K steps per 16-channel chunk
+    constexpr int TAPS = KIND == 0 ? 9 : 4;                   // taps per K step
+    constexpr int HWD = KIND == 1 ? TW + 1 : TW + 2;
+    constexpr int HHT = KIND == 1 ? TH + 1 : TH + 2;
     constexpr int HP = HWD * HHT;
     constexpr int ASLOTS = HP * 4;
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
@@ -806,7 +812,7 @@ conv_halo_emu_kernel(const ConvParams P) {
     constexpr int NGROUPS = (APT + SPT - 1) / SPT;            // <= TAPS
     constexpr int APL = 2 * HP * 16;                          // bytes per term plane (two k-halves)
     constexpr int ACHB = NT * APL;                            // bytes per halo image
-    constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;        // halo pixels between consecutive output rows
+    constexpr int ROWSTEP = HWD;                              // halo pixels between consecutive output rows
 
     extern __shared__ __attribute__((aligned(16))) char smemb[];
     char* As = smemb;                   // [2][ACHB]
@@ -829,7 +835,8 @@ conv_halo_emu_kernel(const ConvParams P) {
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 
     const int q = tid & 3;
-    unsigned spix[APT];
+    unsigned spix[KIND == 1 ? 1 : APT];      // source pixel of a slot (KIND 1: recomputed per phase from siy / six)
+    short siy[KIND == 1 ? APT : 1], six[KIND == 1 ? APT : 1];      // KIND 1: 2 (y0 + hy), 2 (x0 + hx)
     int sdst[APT];           // byte offset of this slot's 4 bf16 inside a term plane
     float smask[KIND == 2 ? APT : 1];
 #pragma unroll
@@ -839,19 +846,18 @@ conv_halo_emu_kernel(const ConvParams P) {
         if (s >= ASLOTS) s -= ASLOTS;
         const int hp = s >> 2;
         const int hy = hp / HWD, hx = hp - hy * HWD;
-        int iy, ix, col = hx;
+        int iy = 0, ix = 0;
+        const int col = hx;
         if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
-        else if (KIND == 1) {
-            iy = reflect1(2 * y0 - 1 + hy, P.H); ix = reflect1(2 * x0 - 1 + hx, P.W);
-            col = (hx & 1) * (HWD / 2) + (hx >> 1);                 // de-interleave even | odd columns
-        } else {
+        else if (KIND == 1) { siy[j] = (short)(2 * (y0 + hy)); six[j] = (short)(2 * (x0 + hx)); }
+        else {
             iy = y0 - 1 + hy; ix = x0 - 1 + hx;
             const bool inside = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
             smask[j] = inside ? 1.f : 0.f;
             iy = min(max(iy, 0), P.H - 1); ix = min(max(ix, 0), P.W - 1);
         }
         sdst[j] = ((q >> 1) * HP + hy * HWD + col) * 16 + (q & 1) * 8;      // k-half = channels 8*(q>>1) .., 4 bf16 at (q&1)*4
-        spix[j] = (unsigned)(iy * P.W + ix);
+        if (KIND != 1) spix[j] = (unsigned)(iy * P.W + ix);
     }
 
     const int nchunks = P.chunks_per_tap;
@@ -862,9 +868,12 @@ conv_halo_emu_kernel(const ConvParams P) {
     // Global operands go through buffer loads: a wave-uniform base (resource + scalar offset) plus ONE 32-bit per-lane
     // offset.  With flat 64-bit addresses the unrolled tap loop keeps a strength-reduced pointer pair per (tap, term)
     // alive across the chunk loop and spills.
-    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; float4 sc, sh; };
-    auto chunk_src = [&](int c) {
+    // K steps: step = chunk * NPH + phase
+    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; int phy, phx; float4 sc, sh; };
+    auto chunk_src = [&](int step) {
         ChunkSrc cs;
+        const int c = step / NPH;
+        cs.phy = (step % NPH) >> 1; cs.phx = (step % NPH) & 1;
         const int s = c < P.chunks0 ? 0 : 1;
         const int cc = (c - (s ? P.chunks0 : 0)) * BK;
         cs.C = (unsigned)P.src_c[s];
@@ -879,7 +888,10 @@ conv_halo_emu_kernel(const ConvParams P) {
         return cs;
     };
     auto load_a = [&](const ChunkSrc& cs, int j) {
-        const unsigned voff = (spix[j] * cs.C + 4u * (unsigned)q) * 4u;
+        unsigned pixel;
+        if (KIND == 1) pixel = (unsigned)(reflect1(siy[j] - cs.phy, P.H) * P.W + reflect1(six[j] - cs.phx, P.W));
+        else pixel = spix[j];
+        const unsigned voff = (pixel * cs.C + 4u * (unsigned)q) * 4u;
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, (int)voff, (int)cs.soff, 0));
     };
     auto store_a = [&](const ChunkSrc& cs, float4 v, int j, char* img) {
@@ -903,8 +915,14 @@ conv_halo_emu_kernel(const ConvParams P) {
 #pragma unroll
     for (int term = 0; term < NT; term++)
         bvoff[term] = ((unsigned)(term * 2 + h) * (unsigned)P.wstride + (unsigned)(n0 + wn0 + l31)) * 16u;
-    auto load_b = [&](vec8 (&dst)[NT][WN], int c, int t) {
-        const unsigned soff = (unsigned)((par * TAPS + t) * nchunks + c) * tile_bytes;      // wave-uniform
+    auto load_b = [&](vec8 (&dst)[NT][WN], int step, int t) {
+        const int c = step / NPH;
+        int tap = par * TAPS + t;
+        if (KIND == 1) {    // tap (a, b) of phase (py, px) is kernel element ky = py ? 2a : 1 + 2a (same for kx)
+            const int phy = (step % NPH) >> 1, phx = (step % NPH) & 1, ta = t >> 1, tb = t & 1;
+            tap = (phy ? 2 * ta : 1 + 2 * ta) * 4 + (phx ? 2 * tb : 1 + 2 * tb);
+        }
+        const unsigned soff = (unsigned)(tap * nchunks + c) * tile_bytes;      // wave-uniform
 #pragma unroll
         for (int term = 0; term < NT; term++)
 #pragma unroll
@@ -921,21 +939,22 @@ conv_halo_emu_kernel(const ConvParams P) {
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
-    const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const int wrow = wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
     const int a_lane_off = (h * HP + wrow + l31) * 16;
 
+    const int s_begin = c_begin * NPH, s_end = c_end * NPH;
     vec8 b[2][NT][WN];
-    if (c_begin < c_end) {
-        const ChunkSrc cs = chunk_src(c_begin);
-        load_b(b[0], c_begin, 0);
+    if (s_begin < s_end) {
+        const ChunkSrc cs = chunk_src(s_begin);
+        load_b(b[0], s_begin, 0);
 #pragma unroll
         for (int j = 0; j < APT; j++)
             if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j, As);
     }
     __syncthreads();
     int cur = 0;
-    for (int c = c_begin; c < c_end; c++, cur ^= 1) {
-        const bool next_chunk = c + 1 < c_end;
+    for (int c = s_begin; c < s_end; c++, cur ^= 1) {            // c = K step (chunk, phase)
+        const bool next_chunk = c + 1 < s_end;
         const ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
         const char* a_rd = As + cur * ACHB + a_lane_off;
         char* a_wr = As + (cur ^ 1) * ACHB;
@@ -963,7 +982,7 @@ conv_halo_emu_kernel(const ConvParams P) {
 #endif
             int aoff;
             if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
-            else if (KIND == 1) aoff = (t >> 2) * HWD + (t & 1) * (HWD / 2) + ((t & 3) >> 1);
+            else if (KIND == 1) aoff = (t >> 1) * HWD + (t & 1);
             else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
             const char* a_s = a_rd + aoff * 16;
             // halo terms are fetched one at a time, smallest first; term ta pairs with the weight terms tb <= NT-1-ta
@@ -1072,8 +1091,10 @@ conv_halo_emu_kernel(const ConvParams P) {
 template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
 static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM;
-    constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds = (size_t)(2 * EmuFmt<FMT>::NT * 32 * HP);
+    constexpr int HP = (KIND == 1 ? 33 : 34) * (KIND == 1 ? TH + 1 : TH + 2);
+    constexpr size_t lds_halo = (size_t)(2 * EmuFmt<FMT>::NT * 32 * HP);
+    constexpr size_t lds_red = (size_t)(WAVES_M * WAVES_N * WN * 32 * 2) * sizeof(float);
+    constexpr size_t lds = lds_halo > lds_red ? lds_halo : lds_red;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN>),
@@ -1362,10 +1383,10 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->bm = 256;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
-    // ... and 64 x 128 tiles (32 x 2 pixels) for the 4x4-s2 convolution, whose halo is 5x the tile
+    // ... the emulated 4x4-s2 convolution runs per input parity phase (conv_halo_emu_kernel): 256-, 128- or 64-row tiles
     if ((d->flags & RNR_CONV_F32_EMU_ANY) && d->kind == RNR_CONV4x4S2_REFLECT && p->cfg == 2 && p->Wo % 32 == 0 &&
         p->Ho % 2 == 0) {
-        p->bm = 64;
+        p->bm = p->Ho % 8 == 0 ? 256 : (p->Ho % 4 == 0 ? 128 : 64);
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
     const int th = p->bm / 32;
@@ -1394,7 +1415,11 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
 
 template <int FMT, int KIND>
 static void launch_halo_emu(const ConvPlan& pl, const dim3 grid, const ConvParams& P, hipStream_t st) {
-    if (KIND == 1) launch_halo_emu_cfg<FMT, 1, 2, 2, 1, 2>(grid, P, st);        // 64 x 128 (make_plan forces the 128-column config)
+    if (KIND == 1) {        // make_plan forces the 128-column config; rows per tile by what divides the map
+        if (pl.bm == 256) launch_halo_emu_cfg<FMT, 1, 2, 2, 4, 2>(grid, P, st);
+        else if (pl.bm == 128) launch_halo_emu_cfg<FMT, 1, 2, 2, 2, 2>(grid, P, st);
+        else launch_halo_emu_cfg<FMT, 1, 2, 2, 1, 2>(grid, P, st);
+    }
     else if (pl.cfg == 0) launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 4, 1, 2, 2>(grid, P, st);         // 256 x 64
     else if (pl.cfg == 1) launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 4, 1, 2, 3>(grid, P, st);         // 256 x 96 (Cout 78)
     else if (pl.bm == 256) launch_halo_emu_cfg<FMT, KIND == 1 ? 0 : KIND, 2, 2, 4, 2>(grid, P, st);        // 256 x 128
@@ -1561,7 +1586,7 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.slab_stride = 0;
     }
     // fp32 emulation on the 16-bit matrix cores: every convolution on the halo plan
-    const bool emu = (d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && (d->kind != RNR_CONV4x4S2_REFLECT || pl.bm == 64);
+    const bool emu = (d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && (d->kind != RNR_CONV4x4S2_REFLECT || pl.cfg == 2);
     if (emu) {
         P.weight_emu = weight_packed + packed_f32_floats(d);
         const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));

@@ -140,6 +140,9 @@ EMU_CASES = [
     (1, 1, 64, 64, [64], 128),         # 4x4 s2, 32x2 tiles
     (1, 2, 64, 128, [32], 16),         # 4x4 s2, narrow output on the 128-column config, two views
     (1, 1, 128, 64, [128], 256),       # 4x4 s2, two column tiles
+    (1, 2, 8, 64, [32], 64),           # 4x4 s2, output 4 rows high: 128-row tiles (per-phase halo 5 x 33)
+    (1, 1, 4, 128, [48], 128),         # 4x4 s2, output 2 rows high: 64-row tiles, three chunks x four phases
+    (1, 1, 512, 512, [16], 128),       # 4x4 s2 at full width: reflection on all four borders, 256-row tiles
     (0, 1, 16, 16, [64, 64], 128),     # map narrower than 32 px: not covered, falls back to the fp32 kernel from the same buffer
 ]
 
