@@ -228,6 +228,89 @@ bin_wide_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ box
     }
 }
 
+// The reference's per-(face, pixel) candidate arithmetic (rasterize_cuda_kernel.cu:115-139) on a 24-float face record
+//   r0 = (x0, y0, x1, y1)  r1 = (x2, y2, x1-x0, y1-y0)  r2 = (x2-x1, y2-y1, x0-x2, y0-y2)
+//   r3 = (inv0..3)  r4 = (inv4..7)  r5 = (inv8, z0, z1, z2)
+// Used by the tile kernel (LDS-broadcast records) and by the face-parallel splat kernel: one definition, so both paths
+// produce the same bits for the same (face, pixel).
+__device__ __forceinline__ bool cand_inside(const float4 r0, const float4 r1, const float4 r2, float xp, float yp) {
+    // inside test (rasterize_cuda_kernel.cu:115-118)
+    if ((yp - r0.y) * r1.z < (xp - r0.x) * r1.w) return false;
+    if ((yp - r0.w) * r2.x < (xp - r0.z) * r2.y) return false;
+    if ((yp - r1.y) * r2.z < (xp - r1.x) * r2.w) return false;
+    return true;
+}
+__device__ __forceinline__ bool cand_depth(const float4 r3, const float4 r4, const float4 r5, float fxi, float fyi,
+                                           float near_, float far_, float& zp, float& w0, float& w1, float& w2) {
+    // w = face_inv * (xi, yi, 1), clamp, renormalise (cu:121-134)
+    w0 = r3.x * fxi + r3.y * fyi + r3.z;
+    w1 = r3.w * fxi + r4.x * fyi + r4.y;
+    w2 = r4.z * fxi + r4.w * fyi + r5.x;
+    w0 = fminf(fmaxf(w0, 0.0f), 1.0f);
+    w1 = fminf(fmaxf(w1, 0.0f), 1.0f);
+    w2 = fminf(fmaxf(w2, 0.0f), 1.0f);
+    float wsum = 0.0f;
+    wsum += w0; wsum += w1; wsum += w2;
+    w0 /= wsum; w1 /= wsum; w2 /= wsum;
+    zp = 1.0f / (w0 / r5.y + w1 / r5.z + w2 / r5.w);   // cu:136
+    return !(zp <= near_ || far_ <= zp);                // cu:137-139 (a NaN zp is rejected by neither test: kept, never wins)
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1c. face-parallel z-resolve for small faces ("splat"): one lane per (view, face) walks the few pixels of the face's
+//     trusted bounding box, runs the reference's candidate arithmetic on each and folds the result into a per-pixel
+//     64-bit key with ONE atomic:  key = (bits of zp) << 32 | face index,  atomicMin.
+//     For zp > 0 the bit pattern of a float orders like the float, so the minimum key is "smallest zp, ties -> smallest
+//     face index" — exactly the order-free form of the reference's rule (ascending faces, strict `<`, cu:142-153) the
+//     tile kernel applies.  zp > near >= 0 is guaranteed by the near test; a NaN zp never passes `zp < far`-style
+//     comparisons and is skipped here just as it never wins there (see cand_depth: NaN is kept by the reject test, so
+//     it is filtered explicitly).  The path is only taken when near >= 0.
+//     Work: faces x box pixels (a pixel-sized face of the bench mesh: ~16-36 tests) instead of tiles x candidates x 256.
+//     Faces whose box cannot be trusted (BOX_EXACT) or covers more than SPLAT_MAX_PIX pixels go to the wide list and
+//     through bin_wide_kernel / the tile kernel as before; the tile kernel merges both results per pixel.
+// ------------------------------------------------------------------------------------------------
+constexpr int SPLAT_MAX_PIX = 256;
+constexpr unsigned long long KEY_EMPTY = ~0ull;
+
+__global__ void __launch_bounds__(256)
+splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ faces_inv, const FaceBox* __restrict__ boxes,
+                   unsigned long long* __restrict__ keys, int* __restrict__ wide_count, int* __restrict__ wide_list,
+                   int batch, int nf, int is, float near_, float far_) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * nf) return;
+    const int bn = (int)(i / nf), fn = (int)(i % nf);
+    const FaceBox b = boxes[i];
+    if (b.xlo != BOX_EXACT && b.xlo > b.xhi) return;                    // empty_box(): culled / off-screen
+    const int xa = max((int)b.xlo, 0), xb = b.xhi, ya = max((int)b.ylo, 0), yb = b.yhi;
+    if (b.xlo == BOX_EXACT || (xb - xa + 1) * (yb - ya + 1) > SPLAT_MAX_PIX) {
+        const int pos = atomicAdd(wide_count + bn, 1);
+        wide_list[(size_t)bn * nf + pos] = fn;
+        return;
+    }
+    const float* f = faces + i * 9;
+    const float* fi = faces_inv + i * 9;
+    const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
+    const float4 r0 = make_float4(x0, y0, x1, y1);
+    const float4 r1 = make_float4(x2, y2, x1 - x0, y1 - y0);
+    const float4 r2 = make_float4(x2 - x1, y2 - y1, x0 - x2, y0 - y2);
+    const float4 r3 = make_float4(fi[0], fi[1], fi[2], fi[3]);
+    const float4 r4 = make_float4(fi[4], fi[5], fi[6], fi[7]);
+    const float4 r5 = make_float4(fi[8], z0, z1, z2);
+    unsigned long long* kv = keys + (size_t)bn * is * is;
+    for (int yi = ya; yi <= yb; yi++) {
+        const float yp = pix_center(yi, is);
+        for (int xi = xa; xi <= xb; xi++) {
+            const float xp = pix_center(xi, is);
+            if (!cand_inside(r0, r1, r2, xp, yp)) continue;
+            float zp, w0, w1, w2;
+            if (!cand_depth(r3, r4, r5, (float)xi, (float)yi, near_, far_, zp, w0, w1, w2)) continue;
+            if (!(zp > 0.0f)) continue;                                 // NaN (and anything the bit order cannot rank)
+            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, zp) << 32) | (unsigned)fn;
+            atomicMin(kv + (size_t)yi * is + xi, key);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. tile kernel
 // ------------------------------------------------------------------------------------------------
@@ -237,6 +320,7 @@ struct RasterParams {
     const FaceBox* boxes;    // [B,nf]
     const int* tile_count;   // [B,ntiles]  candidates binned per tile (may exceed BIN_CAP: then the tile rescans)
     const int* tile_list;    // [B,ntiles,BIN_CAP]
+    const unsigned long long* keys;   // [B,is,is] winners of the face-parallel path (KEY_EMPTY = none) or NULL
     int nf, is;
     float near_, far_;
     int flip;                // 1: write row (is-1-yi)
@@ -309,23 +393,9 @@ raster_tile_kernel(const RasterParams P) {
                 for (int c = 0; c < n; c++) {
                     const float4* rec = reinterpret_cast<const float4*>(s_stage + c * STAGE_FLOATS);
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                    // inside test (rasterize_cuda_kernel.cu:115-118)
-                    if ((yp - r0.y) * r1.z < (xp - r0.x) * r1.w) continue;
-                    if ((yp - r0.w) * r2.x < (xp - r0.z) * r2.y) continue;
-                    if ((yp - r1.y) * r2.z < (xp - r1.x) * r2.w) continue;
-                    const float4 r3 = rec[3], r4 = rec[4], r5 = rec[5];
-                    // w = face_inv * (xi, yi, 1), clamp, renormalise (cu:121-134)
-                    float w0 = r3.x * fxi + r3.y * fyi + r3.z;
-                    float w1 = r3.w * fxi + r4.x * fyi + r4.y;
-                    float w2 = r4.z * fxi + r4.w * fyi + r5.x;
-                    w0 = fminf(fmaxf(w0, 0.0f), 1.0f);
-                    w1 = fminf(fmaxf(w1, 0.0f), 1.0f);
-                    w2 = fminf(fmaxf(w2, 0.0f), 1.0f);
-                    float wsum = 0.0f;
-                    wsum += w0; wsum += w1; wsum += w2;
-                    w0 /= wsum; w1 /= wsum; w2 /= wsum;
-                    const float zp = 1.0f / (w0 / r5.y + w1 / r5.z + w2 / r5.w);   // cu:136
-                    if (zp <= P.near_ || P.far_ <= zp) continue;                    // cu:137-139
+                    if (!cand_inside(r0, r1, r2, xp, yp)) continue;
+                    float zp, w0, w1, w2;
+                    if (!cand_depth(rec[3], rec[4], rec[5], fxi, fyi, P.near_, P.far_, zp, w0, w1, w2)) continue;
                     const int fn = ids[s0 + c];
                     if (zp < best_z || (zp == best_z && best >= 0 && fn < best)) {  // cu:142, order-free form
                         best_z = zp;
@@ -393,6 +463,22 @@ raster_tile_kernel(const RasterParams P) {
     }
 
     if (!in_img) return;
+    if (P.keys) {       // winner of the face-parallel path for this pixel: same rule (smallest zp, then smallest face index)
+        const unsigned long long key = P.keys[((size_t)bn * is + yi) * is + xi];
+        if (key != KEY_EMPTY) {
+            const float kz = __builtin_bit_cast(float, (unsigned)(key >> 32));
+            const int kf = (int)(unsigned)(key & 0xffffffffull);
+            if (kz < best_z || (kz == best_z && best >= 0 && kf < best)) {
+                // recompute this face's weights at this pixel: the same arithmetic on the same inputs, hence the same bits
+                const float* f = faces + (size_t)kf * 9;
+                const float* fi = faces_inv + (size_t)kf * 9;
+                float zp, w0, w1, w2;
+                cand_depth(make_float4(fi[0], fi[1], fi[2], fi[3]), make_float4(fi[4], fi[5], fi[6], fi[7]),
+                           make_float4(fi[8], f[2], f[5], f[8]), fxi, fyi, P.near_, P.far_, zp, w0, w1, w2);
+                best_z = zp; best = kf; bw0 = w0; bw1 = w1; bw2 = w2;
+            }
+        }
+    }
     const int yo = P.flip ? (is - 1 - yi) : yi;
     const size_t pix = ((size_t)bn * is + yo) * is + xi;
 
@@ -544,25 +630,39 @@ static size_t face_bytes(int batch, int nf) { return align_up((size_t)batch * nf
 static int num_tiles(int is) { const int t = (is + TILE - 1) / TILE; return t * t; }
 // binning scratch: [tile_count B*ntiles | wide_count B] (zeroed every call) | tile_list | wide_list
 static size_t bin_counter_bytes(int batch, int is) { return align_up((size_t)batch * (num_tiles(is) + 1) * sizeof(int), 256); }
+static size_t key_bytes(int batch, int is) { return align_up((size_t)batch * is * is * sizeof(unsigned long long), 256); }
 static size_t bin_bytes(int batch, int nf, int is) {
     return bin_counter_bytes(batch, is) + align_up((size_t)batch * num_tiles(is) * BIN_CAP * sizeof(int), 256) +
-           align_up((size_t)batch * nf * sizeof(int), 256);
+           align_up((size_t)batch * nf * sizeof(int), 256) + key_bytes(batch, is);
 }
 
-// Runs the two binning kernels; fills P.tile_count / P.tile_list.
-static int run_binning(char* ws, const float* faces, const FaceBox* boxes, int batch, int nf, int is, RasterParams* P,
-                       hipStream_t st) {
+// Small trusted faces are resolved face-parallel into P.keys (near >= 0), everything else is binned into the tile lists;
+// fills P.tile_count / P.tile_list / P.keys.
+static int run_binning(char* ws, const float* faces, const float* faces_inv, const FaceBox* boxes, int batch, int nf, int is,
+                       RasterParams* P, hipStream_t st) {
     const int ntiles = num_tiles(is);
     int* tile_count = reinterpret_cast<int*>(ws);
     int* wide_count = tile_count + (size_t)batch * ntiles;
     int* tile_list = reinterpret_cast<int*>(ws + bin_counter_bytes(batch, is));
     int* wide_list = reinterpret_cast<int*>(ws + bin_counter_bytes(batch, is) +
                                             align_up((size_t)batch * ntiles * BIN_CAP * sizeof(int), 256));
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(
+        ws + bin_counter_bytes(batch, is) + align_up((size_t)batch * ntiles * BIN_CAP * sizeof(int), 256) +
+        align_up((size_t)batch * nf * sizeof(int), 256));
     RNR_HIP(hipMemsetAsync(tile_count, 0, (size_t)batch * (ntiles + 1) * sizeof(int), st));
     const long total = (long)batch * nf;
-    hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, boxes, tile_count,
-                       tile_list, wide_count, wide_list, batch, nf, is);
-    if (int e = check_launch("bin_faces_kernel")) return e;
+    const bool splat = P->near_ >= 0.0f;            // the key order needs zp > 0, which the near test then guarantees
+    if (splat) {
+        RNR_HIP(hipMemsetAsync(keys, 0xFF, (size_t)batch * is * is * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(splat_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, faces_inv, boxes,
+                           keys, wide_count, wide_list, batch, nf, is, P->near_, P->far_);
+        if (int e = check_launch("splat_faces_kernel")) return e;
+        P->keys = keys;
+    } else {
+        hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, boxes, tile_count,
+                           tile_list, wide_count, wide_list, batch, nf, is);
+        if (int e = check_launch("bin_faces_kernel")) return e;
+    }
     hipLaunchKernelGGL(bin_wide_kernel, dim3(512, batch), dim3(256), 0, st, faces, boxes, tile_count, tile_list, wide_count,
                        wide_list, nf, is);
     if (int e = check_launch("bin_wide_kernel")) return e;
@@ -601,8 +701,8 @@ extern "C" int rnr_forward_face_index_map(const float* faces, int32_t* face_inde
     P.near_ = near_; P.far_ = far_; P.flip = 0;
     P.face_index_map = face_index_map; P.weight_map = weight_map; P.depth_map = depth_map;
     P.face_inv_map = return_depth ? face_inv_map : nullptr;
-    if (int e = run_binning(reinterpret_cast<char*>(workspace) + box_bytes(batch_size, num_faces), faces, boxes, batch_size,
-                            num_faces, image_size, &P, st)) return e;
+    if (int e = run_binning(reinterpret_cast<char*>(workspace) + box_bytes(batch_size, num_faces), faces, faces_inv, boxes,
+                            batch_size, num_faces, image_size, &P, st)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<0>, dim3(tiles * tiles, batch_size), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<0>");
@@ -657,8 +757,8 @@ extern "C" int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, c
     P.faces = faces; P.faces_inv = faces_inv; P.boxes = boxes; P.nf = nf; P.is = image_size;
     P.near_ = near_; P.far_ = far_; P.flip = 1;
     P.mesh = *mesh; P.gb = *out; P.pose = pose;
-    if (int e = run_binning(ws + box_bytes(num_views, nf) + 2 * face_bytes(num_views, nf), faces, boxes, num_views, nf,
-                            image_size, &P, st)) return e;
+    if (int e = run_binning(ws + box_bytes(num_views, nf) + 2 * face_bytes(num_views, nf), faces, faces_inv, boxes, num_views,
+                            nf, image_size, &P, st)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<1>, dim3(tiles * tiles, num_views), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<1>");

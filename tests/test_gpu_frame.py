@@ -121,25 +121,39 @@ def test_frame512_nf64_vs_oracle(precision):
         assert (one - img8[i:i + 1]).abs().max() <= 1e-5, i
 
 
-def test_frame1024_c16_vs_oracle():
-    """BASELINE config 5 shape class: 1024x1024, 16-channel neural texture (U-Net input 78 + 6 + 16 = 100 -> 78),
-    lighting from a 4096-sample SH projection of an environment map (lmax 10).  Small nf0 keeps the CPU oracle fast."""
+@pytest.mark.parametrize('nf0,precision', [(8, 'f32'), (64, 'f32'), (64, 'f16x3')])
+def test_frame1024_c16_vs_oracle(nf0, precision):
+    """BASELINE config 5 on one GPU: 1024x1024, 16-channel neural texture (U-Net input 78 + 6 + 16 = 100 -> 78), lighting
+    from an environment map through the reference's front-end classes: network.LightingLP (probe -> area resize ->
+    4096 bilinear samples -> SH fit, lmax 10) -> network.LightingSH -> light probe.  nf0 = 64 is the real network width
+    (one view: ~25 s of CPU oracle), nf0 = 8 the quick variant."""
+    import network
     from oracle import rnr_oracle as orc
-    from rnr_amd import lighting, scene, testing
+    from rnr_amd import scene, testing
     from rnr_amd.pipeline import RNRPipeline
     S = 1024
-    sc = testing.tiny_scene(img_size=S, nf0=8, tex_size=256, tex_ch=16, nlat=24, nlon=48, seed=2)
-    env = testing.synthetic_light_probe(160, 320, 7)[0]
+    sc = testing.tiny_scene(img_size=S, nf0=nf0, tex_size=256, tex_ch=16, nlat=24, nlon=48, seed=2)
+    env = testing.synthetic_light_probe(400, 800, 7)[0]
     l_dir = T(scene.sphere_samples(4096)).t().contiguous()
-    coeff, _, _ = lighting.envmap_to_sh(env.to(DEV), l_dir.to(DEV), 10)
-    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=8,
-                       max_views=1, device=DEV, sh_coeff=coeff[None], sh_lmax=10)
+    lp_model = network.LightingLP(l_dir, num_channel=3, lp_dataloader=[{'lp_img': env.permute(2, 0, 1)[None]}],
+                                  fix_params=True, lp_img_h=160, lp_img_w=320, device=DEV)
+    lp_model.fit_sh(lmax=10)
+    coeff = lp_model.sh_coeff.to(DEV)                       # [1,121,3]
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=nf0,
+                       max_views=1, device=DEV, sh_coeff=coeff, sh_lmax=10, precision=precision)
     views = {k: T(v) for k, v in scene.spiral_views(S, [77]).items()}
     dv = {k: v.to(DEV) for k, v in views.items()}
     img = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True).cpu()
     assert pipe.unet.in_c_pad == 112 and pipe.c_in == 100
+    # oracle: same chain on the CPU (resize -> samples -> fit -> reconstruct), then the frame
+    small = T(orc.resize_area(env.numpy(), 160, 320))
+    uv = orc.spherical_mapping(l_dir)
+    samples = orc.interpolate_bilinear(small, (uv[0] * 320.0).clamp(max=319), (uv[1] * 160.0).clamp(max=159))
+    basis_l = torch.from_numpy(orc.sh_basis(10, l_dir.t().numpy()).astype(np.float32))
+    coeff_ref = orc.fit_sh_coeff(samples, basis_l)
+    assert (coeff[0].cpu() - coeff_ref).abs().max() < 2e-5
     basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
-    lp = orc.reconstruct_lp(coeff.cpu(), basis)[None]
+    lp = orc.reconstruct_lp(coeff_ref, basis)[None]
     mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
     ref = orc.render_frame(mesh_t, views, S, sc['textures'], sc['unet_sd'], lp, sc['pivots_spec'], sc['pivots_diff'])
     assert (pipe.last['gb']['face_index_map'].cpu() != ref['face_index_map']).float().mean() < 1e-3
