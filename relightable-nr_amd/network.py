@@ -100,22 +100,33 @@ class Rasterizer(nn.Module):
         renderer.anti_aliasing = False
         renderer.fill_back = False
         self.renderer = renderer
-        self._mesh = None
+        self._mesh = {}
 
     def _apply(self, fn, *a, **k):
-        self._mesh = None
+        self._mesh = {}
         return super()._apply(fn, *a, **k)
 
-    def _device_mesh(self):
-        if self._mesh is None:
-            self._mesh = ops.DeviceMesh(self.vertices[0], self.vertices_texcoords[0], self.vertices_normals[0],
-                                        self.faces[0], self.faces_vt_idx[0], self.faces_vn_idx[0], self.vertices.device)
-        return self._mesh
+    @staticmethod
+    def _both_sides(idx):
+        """renderer.py:209-211 / network.py:183-185: every face once more with reversed vertex order."""
+        return torch.cat((idx, idx[:, :, [2, 1, 0]]), dim=1).contiguous()
+
+    def _device_mesh(self, fill_back=False):
+        if fill_back not in self._mesh:
+            f = self._both_sides if fill_back else (lambda x: x)
+            self._mesh[fill_back] = ops.DeviceMesh(self.vertices[0], self.vertices_texcoords[0], self.vertices_normals[0],
+                                                   f(self.faces)[0], f(self.faces_vt_idx)[0], f(self.faces_vn_idx)[0],
+                                                   self.vertices.device)
+        return self._mesh[fill_back]
 
     def forward(self, proj, pose, dist_coeffs, offset, scale):
-        if self.renderer.fill_back or self.renderer.anti_aliasing:
-            raise NotImplementedError('Rasterizer: fill_back / anti_aliasing are off on the hot path (network.py:152-153)')
-        mesh = self._device_mesh()
+        if self.renderer.anti_aliasing:
+            # the reference's own forward cannot run with it either: nr.Renderer.render returns face_index_map / weight_map
+            # at 2x resolution next to a pooled depth (rasterize.py:296-330), and network.py:178 multiplies the two
+            raise NotImplementedError('Rasterizer: anti_aliasing=True is not usable through network.Rasterizer.forward '
+                                      '(shape mismatch at network.py:178 in the reference itself); use nr.Renderer directly')
+        fill_back = bool(self.renderer.fill_back)
+        mesh = self._device_mesh(fill_back)
         S = self.img_size
         N = proj.shape[0]
         R = pose[:, :3, :3].float().contiguous()
@@ -131,9 +142,11 @@ class Rasterizer(nn.Module):
         v_uvz[..., 1] = (1 - (v_uvz[..., 1] * 0.5 + 0.5)) * S
         v_depth = misc.interpolate_bilinear(depth[0, :, :, None].contiguous(), v_uvz[..., 0], v_uvz[..., 1])
         v_front_mask = ((v_uvz[0, :, 2] - v_depth[0, :, 0]) < self.mesh_span.to(depth.device) * 5e-3)[None, :]
-        faces_v = nr.vertex_attrs_to_faces(self.vertices, self.faces)
-        faces_vt = nr.vertex_attrs_to_faces(self.vertices_texcoords, self.faces_vt_idx)
-        return (gb['uv_map'], gb['alpha'], gb['face_index_map'], gb['weight_map'][..., None], self.faces, gb['normal_map'],
+        faces_v_idx = self._both_sides(self.faces) if fill_back else self.faces
+        faces_v = nr.vertex_attrs_to_faces(self.vertices, faces_v_idx)
+        faces_vt = nr.vertex_attrs_to_faces(self.vertices_texcoords,
+                                            self._both_sides(self.faces_vt_idx) if fill_back else self.faces_vt_idx)
+        return (gb['uv_map'], gb['alpha'], gb['face_index_map'], gb['weight_map'][..., None], faces_v_idx, gb['normal_map'],
                 gb['normal_map_cam'], faces_v, faces_vt, gb['position_map'], gb['position_map_cam'], depth[..., None],
                 v_uvz, v_front_mask)
 

@@ -355,3 +355,47 @@ def test_extension_accepts_float64(golden):
     with pytest.raises(RuntimeError):
         ext.forward_face_index_map(f64, fim, wm.float(), dm, fivm, finv, S, 0.0, far, 1, 1, 1)
 
+
+def test_rasterizer_fill_back(golden, tmp_path):
+    """network.Rasterizer with renderer.fill_back = True (renderer.py:209-211, network.py:183-198): every face once more with
+    reversed winding, so the far side of the mesh is drawn where the near side is cut away (here: near plane through the
+    sphere).  Compared with the oracle run on the explicitly doubled mesh; anti_aliasing raises with the reason."""
+    import network
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    g = golden('rasterizer_module64')
+    mesh = {k: g['mesh_' + k] for k in ['v', 'vt', 'vn', 'f_v_idx', 'f_vt_idx', 'f_vn_idx']}
+    fp = str(tmp_path / 'm.obj')
+    scene.write_obj(fp, mesh)
+    ras = network.Rasterizer(fp, 64).to(DEV)
+    ras.renderer.fill_back = True
+    ras.renderer.near = 2.9                       # camera at radius 3, unit sphere: the near plane cuts the front cap off
+    views = scene.spiral_views(64, [11])
+    proj, pose = T(views['proj']).to(DEV), T(views['pose']).to(DEV)
+    out = ras(proj, pose, None, None, None)
+    fim = out[2].cpu()
+    nf = mesh['f_v_idx'].shape[0]
+    assert int((fim >= nf).sum()) > 50            # back faces (second copy) are visible through the cut
+    assert tuple(out[4].shape) == (1, 2 * nf, 3) and tuple(out[7].shape) == (1, 2 * nf, 3, 3)
+    rev = lambda a: np.concatenate([a, a[:, ::-1]], 0)
+    mesh2 = {k: T(np.ascontiguousarray(v)) for k, v in mesh.items()}
+    for k in ['f_v_idx', 'f_vt_idx', 'f_vn_idx']:
+        mesh2[k] = T(np.ascontiguousarray(rev(mesh[k])))
+    v_ndc = ops_project(ras, proj, pose)
+    ref = orc.rasterizer_forward(mesh2, T(views['proj']), T(views['pose']), 64, near=2.9, v_uvz_ndc=v_ndc.cpu())
+    assert torch.equal(fim, ref['face_index_map'])
+    for i, k in [(0, 'uv_map'), (5, 'normal_map'), (9, 'position_map')]:
+        d = (out[i].cpu() - ref[k]).abs()
+        if k == 'uv_map':
+            d = torch.minimum(d, 1.0 - d)
+        assert d.max() < 5e-6, (k, d.max())
+    ras.renderer.anti_aliasing = True
+    with pytest.raises(NotImplementedError):
+        ras(proj, pose, None, None, None)
+
+
+def ops_project(ras, proj, pose):
+    from rnr_amd import ops
+    return ops.project_vertices(ras.vertices[0].contiguous(), proj, pose[:, :3, :3].contiguous(), pose[:, :3, 3].contiguous(),
+                                ras.img_size)
+
