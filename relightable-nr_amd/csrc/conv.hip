@@ -1000,9 +1000,6 @@ conv_halo_emu_kernel(const ConvParams P) {
                         for (int j = 0; j < WN; j++)
                             acc[i][j] = F::mfma(a[i], b[t & 1][tb][j], acc[i][j]);
             }
-#ifdef RNR_EMU2_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);      // keep the taps apart: no hoisting of later taps' LDS reads
-#endif
         }
 #ifndef RNR_ABLATE_EMU_NOHALO
         if (next_chunk && NGROUPS == TAPS) {        // the slice loaded during the last tap

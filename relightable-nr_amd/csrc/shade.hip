@@ -240,8 +240,10 @@ shade_inputs_kernel(const ShadeParams P) {
     // the 32 banks: conflict-free), and reads the geometry record of only ~3 pixels (LDS broadcast).  With the pixel
     // fastest every lane of a wave hit one of two banks (row stride 112 floats = 16 mod 32): 16-way conflicts,
     // 72 M conflict cycles per dispatch in the round-1 profile.
+    const float inv_rays = 1.0f / (float)n_rays;
     for (int i = tid; i < SH_PIX * n_rays; i += SH_THREADS) {
-        const int p = i / n_rays, r = i - p * n_rays;
+        const int p = (int)(((float)i + 0.5f) * inv_rays), r = i - p * n_rays;      // exact i / n_rays for i < 2^20
+
         const float* g = geo + p * GEO;
         const float3 tt = f3(g[0], g[1], g[2]), bt = f3(g[3], g[4], g[5]), nm = f3(g[6], g[7], g[8]);
         const float a = g[14];
@@ -277,8 +279,9 @@ shade_inputs_kernel(const ShadeParams P) {
 
     // ---- phase 2: (pixel, channel-quad) items: sum over levels of bilinear fetches (network.py:71-85) ----
     const int quads = P.C / 4;
+    const float inv_quads = 1.0f / (float)quads;
     for (int i = tid; i < SH_PIX * quads; i += SH_THREADS) {
-        const int q = i % quads, p = i / quads;
+        const int p = (int)(((float)i + 0.5f) * inv_quads), q = i - p * quads;
         const float* g = geo + p * GEO;
         const float u = g[12], v = g[13];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -460,23 +463,31 @@ ray_render_kernel(const RayParams P) {
         const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
         tp[k] = bilinear_taps(x, y, P.lp_w, P.lp_h);
     }
+    // mean over the rays of a group as a multiplication by the reciprocal (one division per thread instead of six
+    // correctly rounded ones per pixel; <= 1 ulp from network.py:505-513's `.sum(1) / num_ray`)
+    const float inv_spec = 1.0f / (float)P.n_spec;
+    const float inv_diff = P.n_diff > 0 ? 1.0f / (float)P.n_diff : 0.0f;
     float c0[RR_PIX], c1[RR_PIX], c2[RR_PIX];
 #pragma unroll
     for (int k = 0; k < RR_PIX; k++) {
         c0[k] = c1[k] = c2[k] = 0.f;
         if (live[k]) {
             const Taps& t = tp[k];
+#ifdef RNR_ABLATE_RAY_FIXEDTAP
+            const float* l00 = P.lp + (unsigned)(sub * 3); const float* l10 = l00 + 3; const float* l01 = l00 + 6; const float* l11 = l00 + 9;
+#else
             const float* l00 = P.lp + (unsigned)((t.y0 * P.lp_w + t.x0) * 3);
             const float* l10 = P.lp + (unsigned)((t.y1 * P.lp_w + t.x0) * 3);
             const float* l01 = P.lp + (unsigned)((t.y0 * P.lp_w + t.x1) * 3);
             const float* l11 = P.lp + (unsigned)((t.y1 * P.lp_w + t.x1) * 3);
+#endif
             const float col0 = l00[0] * t.w00 + l10[0] * t.w10 + l01[0] * t.w01 + l11[0] * t.w11;
             const float col1 = l00[1] * t.w00 + l10[1] * t.w10 + l01[1] * t.w01 + l11[1] * t.w11;
             const float col2 = l00[2] * t.w00 + l10[2] * t.w10 + l01[2] * t.w01 + l11[2] * t.w11;
-            // network.py:253 tanh; test_rnr.py:359 (y*0.5+0.5)*2
-            c0[k] = (fast_tanhf(y0[k] + b0) * 0.5f + 0.5f) * 2.0f * col0;
-            c1[k] = (fast_tanhf(y1[k] + b1) * 0.5f + 0.5f) * 2.0f * col1;
-            c2[k] = (fast_tanhf(y2[k] + b2) * 0.5f + 0.5f) * 2.0f * col2;
+            // network.py:253 tanh; test_rnr.py:359 (y*0.5+0.5)*2 == y + 1 bit for bit (the two scalings by 2 are exact)
+            c0[k] = (fast_tanhf(y0[k] + b0) + 1.0f) * col0;
+            c1[k] = (fast_tanhf(y1[k] + b1) + 1.0f) * col1;
+            c2[k] = (fast_tanhf(y2[k] + b2) + 1.0f) * col2;
             // background pixels contribute exactly 0 whatever the network produced there (col = 0 by the uv = -1
             // mask); select rather than multiply: the out layer may have skipped the tile (rnr_conv2d_masked) and
             // left non-finite garbage.  Done here, after every load has landed, so the loads stay independent.
@@ -495,8 +506,8 @@ ray_render_kernel(const RayParams P) {
             const float o[3] = {s0, s1, s2}, dd[3] = {d0, d1, d2};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                float out = ni[P.alb_spec_ch + c] * (o[c] / (float)P.n_spec);
-                if (P.n_diff > 0) out = out + ni[P.alb_diff_ch + c] * (dd[c] / (float)P.n_diff);
+                float out = ni[P.alb_spec_ch + c] * (o[c] * inv_spec);
+                if (P.n_diff > 0) out = out + ni[P.alb_diff_ch + c] * (dd[c] * inv_diff);
                 P.image[(n * 3 + c) * P.hw + rem] = out;
             }
         }
