@@ -436,7 +436,7 @@ def main():
                         'frames_per_s': args.steps * V / dt4, 'ms_per_step': dt4 / args.steps * 1e3,
                         'note': 'RNRPipeline(precision="f16x3", skip_background_tiles=True), one stream; not the headline value'}
                 del pe
-        if world == 1 and V > 1 and extras and not fast:
+        if world == 1 and V > 1 and extras and (not fast or os.environ.get('RNR_BENCH_SINGLE') == '1'):
             # the reference renders one view per call (test_rnr.py:265): also report that latency-oriented mode
             # (same pipeline, 1 pose per step; outside the timed region above)
             def one(s):

@@ -22,6 +22,7 @@
 #include "rnr_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rnr {
 
@@ -1101,18 +1102,47 @@ static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_
     hipLaunchKernelGGL((conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
 }
 
+// Wave quantisation of small grids.  With n tiles per CU and s co-resident workgroups per CU the grid runs in
+// ceil(n / s) rounds; a last round of ONE workgroup per CU leaves a single wave per SIMD, which cannot keep the matrix
+// pipe busy (measured on the 64-column layers at one view per call: 4 tiles per CU on 3 slots = 3 + 1 -> 60 % of the
+// peak, 2 + 2 on two slots -> 80 %).  Model: a round of r co-resident workgroups costs r / eff(r) tile-times with
+// eff = 0.55 / 0.86 / 0.90 for r = 1 / 2 / 3; pick the slot count (<= what registers and LDS allow) with the smallest
+// total.  Large grids (>= 4 rounds) keep the maximum.  RNR_HALO_SLOTS=k forces k (experiments).
+static int balanced_slots(long tiles, int max_slots) {
+    static const int forced = [] { const char* e = getenv("RNR_HALO_SLOTS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced < max_slots ? forced : max_slots;
+    const long n = (tiles + 255) / 256;            // tiles per CU (256 CUs)
+    if (n >= 4L * max_slots || max_slots <= 1) return max_slots;
+    static const double eff[4] = {0.0, 0.55, 0.86, 0.90};
+    int best = max_slots;
+    double best_t = 1e30;
+    for (int s = max_slots; s >= 1; s--) {
+        const long full = n / s, rem = n % s;
+        double t = (double)full * s / eff[s < 3 ? s : 3];
+        if (rem) t += (double)rem / eff[rem < 3 ? rem : 3];
+        if (t < best_t - 1e-9) { best_t = t; best = s; }
+    }
+    return best;
+}
+
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM, BN = WAVES_N * (WN * 32 + R16 * 16);
     constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
     constexpr size_t lds_halo = (size_t)((KIND == 1 ? 1 : 2) * BK * HP) * sizeof(float);
     constexpr size_t lds_red = (size_t)(WAVES_M * BN * 2) * sizeof(float);         // statistics reduction of the epilogue
-    constexpr size_t lds = lds_halo > lds_red ? lds_halo : lds_red;
-    static bool attr_set = false;
-    if (!attr_set) {    // > 64 KiB of dynamic LDS needs the opt-in
+    constexpr size_t lds_min = lds_halo > lds_red ? lds_halo : lds_red;
+    // workgroups per CU the registers allow (the kernel's __launch_bounds__) and LDS allows
+    constexpr int nat = (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1);
+    constexpr int lds_slots = (int)((160 * 1024) / lds_min);
+    const int slots = balanced_slots((long)grid.x, nat < lds_slots ? nat : lds_slots);
+    // fewer co-resident workgroups are requested by padding the dynamic LDS allocation
+    const size_t lds = slots < lds_slots ? (size_t)(160 * 1024 / slots) & ~(size_t)255 : lds_min;
+    static size_t attr_set = 0;
+    if (attr_set < lds) {    // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set = lds;
     }
     hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>), grid, dim3(CTHREADS), lds, st, P);
 }
