@@ -245,7 +245,7 @@ typedef struct rnr_conv_desc {
 /* fp32 emulation on the fp16 matrix cores: every operand is split into TWO fp16 terms (22 significand bits, relative
  * representation error <= 2^-23) and the three leading partial products (hh, hl, lh) are accumulated in fp32 by
  * v_mfma_f32_32x32x16_f16: 5.3x fewer MFMA cycles than the exact-fp32 kernel, half of bf16x6.  Measured error against a
- * float64 convolution is below the exact-fp32 kernel's on every U-Net layer shape (fewer accumulator roundings outweigh
+ * float64 convolution is below the exact-fp32 kernel's on every U-Net layer shape it covers (fewer accumulator roundings outweigh
  * the two missing significand bits; tests/test_gpu_unet.py).  Weights are pre-scaled per layer by a power of two at pack
  * time (undone exactly in the epilogue), so any finite weights are fine; activations must satisfy
  * |act(scale * x + shift)| < 65504 — true for BatchNorm outputs and bounded network inputs; values below 2^-14 keep an

@@ -25,8 +25,8 @@ LAYERS = [(1, 0, 512, [108], 64), (2, 0, 512, [64], 64), (3, 1, 512, [64], 128),
 
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
-    print('| # | op | in HxW | Cin -> Cout | K | rel rms f32 MFMA | bf16x6 | ratio | f16x3 | ratio |')
-    print('|--:|---|---|---|--:|--:|--:|--:|--:|--:|')
+    print('| # | op | in HxW | Cin -> Cout | K | split-K f32 / emu | rel rms f32 MFMA | bf16x6 | ratio | f16x3 | ratio |')
+    print('|--:|---|---|---|--:|---|--:|--:|--:|--:|--:|')
     worst = {'bf16x6': 0.0, 'f16x3': 0.0}
     for idx, kind, H, cins, cout in LAYERS:
         g = torch.Generator().manual_seed(100 + idx)
@@ -48,11 +48,23 @@ def main():
             out, _ = tu.run_conv(kind, srcs, w, cout, 1, H, H, flags=flag)
             rel[name] = float((out[..., :cout].double() - ref).pow(2).mean().sqrt() / den)
         K = cin * (9 if kind == 0 else (16 if kind == 1 else 4))
+        # split-K depth each path uses at this batch of 1 (workspace = splitk x output bytes + 256): partial sums in
+        # separate slabs shorten the fp32 accumulation chains, which lowers the error of whichever path splits
+        import ctypes
+        L = _lib.load()
+        pad16 = lambda c: (c + 15) // 16 * 16
+        oh = H if kind == 0 else (H // 2 if kind == 1 else 2 * H)
+        sk = {}
+        for name, flag in [('f32', 0), ('emu', _lib.CONV_F32_EMU_F16X3)]:
+            desc = _lib.RnrConvDesc(kind, cins[0], pad16(cins[0]), cins[1] if len(cins) > 1 else 0,
+                                    pad16(cins[1]) if len(cins) > 1 else 0, cout, pad16(cout), flag)
+            ws = L.rnr_conv_workspace_bytes(ctypes.byref(desc), 1, H, H)
+            sk[name] = max(1, (ws - 256) // (oh * oh * pad16(cout) * 4)) if ws > 256 else 1
         op = ['conv3x3', 'conv4x4 s2', 'convT4x4 s2'][kind]
         for n in worst:
             worst[n] = max(worst[n], rel[n] / rel['f32'])
-        print('| %d | %s | %d^2 | %s -> %d | %d | %.3e | %.3e | %.2f | %.3e | %.2f |' % (
-            idx, op, H, '+'.join(map(str, cins)), cout, K, rel['f32'], rel['bf16x6'], rel['bf16x6'] / rel['f32'], rel['f16x3'],
+        print('| %d | %s | %d^2 | %s -> %d | %d | %d / %d | %.3e | %.3e | %.2f | %.3e | %.2f |' % (
+            idx, op, H, '+'.join(map(str, cins)), cout, K, sk['f32'], sk['emu'], rel['f32'], rel['bf16x6'], rel['bf16x6'] / rel['f32'], rel['f16x3'],
             rel['f16x3'] / rel['f32']))
         sys.stdout.flush()
     print()
