@@ -241,6 +241,9 @@ shade_inputs_kernel(const ShadeParams P) {
     // fastest every lane of a wave hit one of two banks (row stride 112 floats = 16 mod 32): 16-way conflicts,
     // 72 M conflict cycles per dispatch in the round-1 profile.
     const float inv_rays = 1.0f / (float)n_rays;
+#ifdef RNR_ABLATE_SH_NORAYS
+    if (false)
+#endif
     for (int i = tid; i < SH_PIX * n_rays; i += SH_THREADS) {
         const int p = (int)(((float)i + 0.5f) * inv_rays), r = i - p * n_rays;      // exact i / n_rays for i < 2^20
 
@@ -280,6 +283,9 @@ shade_inputs_kernel(const ShadeParams P) {
     // ---- phase 2: (pixel, channel-quad) items: sum over levels of bilinear fetches (network.py:71-85) ----
     const int quads = P.C / 4;
     const float inv_quads = 1.0f / (float)quads;
+#ifdef RNR_ABLATE_SH_NOTEX
+    if (false)
+#endif
     for (int i = tid; i < SH_PIX * quads; i += SH_THREADS) {
         const int p = (int)(((float)i + 0.5f) * inv_quads), q = i - p * quads;
         const float* g = geo + p * GEO;
@@ -323,6 +329,9 @@ shade_inputs_kernel(const ShadeParams P) {
     const int n4 = (int)(valid_pix * cp / 4);
     float4* dst = reinterpret_cast<float4*>(P.net_in + pix0 * cp);
     const float4* src = reinterpret_cast<const float4*>(tile);
+#ifdef RNR_ABLATE_SH_NOSTORE
+    if (blockIdx.x == 0x7fffffff)
+#endif
     for (int i = tid; i < n4; i += SH_THREADS) dst[i] = src[i];
     if (P.neural_img) {  // [N, C, H, W] copy for the API (TextureMapper.forward's return value)
         const int hw = P.H * P.W;

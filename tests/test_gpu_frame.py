@@ -55,6 +55,27 @@ def test_frame256_vs_oracle():
     assert p > 55.0, p
 
 
+@pytest.mark.parametrize('S,precision', [(96, 'f32'), (160, 'f32'), (160, 'f16x3'), (96, 'bf16x6')])
+def test_frame_sizes_not_power_of_two(S, precision):
+    """Image sizes 3 x 32 and 5 x 32: U-Net levels 96..3 / 160..5 (odd maps at the bottom, maps narrower than 32 px on the
+    gather kernel, halo tiles of 4 and 8 rows, ragged raster tiles at S = 96 / 160 -> 6 / 10 tiles of 16)."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    sc = testing.tiny_scene(img_size=S, nf0=8, tex_size=64, tex_ch=24, nlat=31, nlon=62, seed=6)
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], sc['lp'], nf0=8,
+                       max_views=3, device=DEV, precision=precision)
+    views = {k: T(v) for k, v in scene.spiral_views(S, [15, 333, 600]).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    img = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True).cpu()
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    gb = orc.rasterizer_forward(mesh_t, views['proj'], views['pose'], S, v_uvz_ndc=pipe.last['v_uvz'].cpu())
+    assert torch.equal(pipe.last['gb']['face_index_map'].cpu(), gb['face_index_map'])
+    ref = orc.render_frame(mesh_t, views, S, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'], sc['pivots_diff'])
+    p = orc.psnr(img, ref['image'])
+    assert p > 55.0, p
+
+
 def _bench_scene():
     """The BASELINE configs[2] workload exactly as bench.py builds it: UV-sphere 128 x 256 (65 536 faces), neural texture
     512^2 x 24 ch x 4 levels, RenderingNet 108 -> 78 with nf0 = 64, SH lighting lmax 10, 512^2."""
