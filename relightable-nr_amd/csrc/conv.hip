@@ -788,14 +788,17 @@ constexpr int EMU_HEADER_BYTES = 64;     // packed emulation image: [0] float 2^
 //     of the split sits in the issue slots between MFMAs instead of in a burst between two barriers.
 // Two workgroups (2 x 4 waves) per CU: two waves per SIMD cover each other's operand waits.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int TW>
 __global__ void __launch_bounds__(CTHREADS, 2)
 conv_halo_emu_kernel(const ConvParams P) {
     typedef EmuFmt<FMT> F;
     typedef typename F::vec8 vec8;
     constexpr int NT = F::NT;
     static_assert(WAVES_M * WAVES_N == 4 && BK == 16, "four waves, 16-channel chunks");
-    constexpr int TW = 32, TH = WAVES_M * WM;
+    // TW = 32: a 32-row MFMA block is one image row of the tile; TW = 16 (maps 16 pixels wide): two image rows
+    static_assert(TW == 32 || TW == 16, "tile width");
+    constexpr int RPB = 32 / TW;                              // image rows per MFMA row block
+    constexpr int TH = WAVES_M * WM * RPB;
     constexpr int BN = WAVES_N * WN * 32;
     // KIND 1 (4x4 stride 2) runs as FOUR stride-1 2x2-tap convolutions, one per input parity phase (py, px): input
     // row 2y + ky - 1 = 2(y + ty) + py with (ky; ty, py) = (0; -1, 1), (1; 0, 0), (2; 0, 1), (3; 1, 0).  A K step is a
@@ -813,7 +816,7 @@ conv_halo_emu_kernel(const ConvParams P) {
     constexpr int NGROUPS = (APT + SPT - 1) / SPT;            // <= TAPS
     constexpr int APL = 2 * HP * 16;                          // bytes per term plane (two k-halves)
     constexpr int ACHB = NT * APL;                            // bytes per halo image
-    constexpr int ROWSTEP = HWD;                              // halo pixels between consecutive output rows
+    constexpr int ROWSTEP = RPB * HWD;                        // halo pixels between consecutive MFMA row blocks
 
     extern __shared__ __attribute__((aligned(16))) char smemb[];
     char* As = smemb;                   // [2][ACHB]
@@ -940,8 +943,8 @@ conv_halo_emu_kernel(const ConvParams P) {
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
-    const int wrow = wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
-    const int a_lane_off = (h * HP + wrow + l31) * 16;
+    const int wrow = wave_m * WM * RPB * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const int a_lane_off = (h * HP + wrow + (l31 / TW) * HWD + (l31 % TW)) * 16;
 
     const int s_begin = c_begin * NPH, s_end = c_end * NPH;
     vec8 b[2][NT][WN];
@@ -1033,10 +1036,11 @@ conv_halo_emu_kernel(const ConvParams P) {
     float* out = P.out + (size_t)split * P.slab_stride;
 #pragma unroll
     for (int i = 0; i < WM; i++) {
-        const int y = y0 + wave_m * WM + i;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
-            const int x = x0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int pb = (g & 3) + 8 * (g >> 2) + 4 * h;          // pixel of the 32-row block this accumulator element holds
+            const int y = y0 + (wave_m * WM + i) * RPB + pb / TW;
+            const int x = x0 + pb % TW;
             const size_t off = (KIND == 2)
                 ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
                 : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
@@ -1086,20 +1090,20 @@ conv_halo_emu_kernel(const ConvParams P) {
     }
 }
 
-template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int FMT, int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int TW = 32>
 static void launch_halo_emu_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
-    constexpr int TH = WAVES_M * WM;
-    constexpr int HP = (KIND == 1 ? 33 : 34) * (KIND == 1 ? TH + 1 : TH + 2);
+    constexpr int TH = WAVES_M * WM * (32 / TW);
+    constexpr int HP = (KIND == 1 ? TW + 1 : TW + 2) * (KIND == 1 ? TH + 1 : TH + 2);
     constexpr size_t lds_halo = (size_t)(2 * EmuFmt<FMT>::NT * 32 * HP);
     constexpr size_t lds_red = (size_t)(WAVES_M * WAVES_N * WN * 32 * 2) * sizeof(float);
     constexpr size_t lds = lds_halo > lds_red ? lds_halo : lds_red;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN, TW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN>), grid, dim3(CTHREADS), lds, st, P);
+    hipLaunchKernelGGL((conv_halo_emu_kernel<FMT, KIND, WAVES_M, WAVES_N, WM, WN, TW>), grid, dim3(CTHREADS), lds, st, P);
 }
 
 // Wave quantisation of small grids.  With n tiles per CU and s co-resident workgroups per CU the grid runs in
@@ -1371,6 +1375,7 @@ struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
+    int tw;         // pixel-tile width of the halo plan: 32, or 16 (emulation kernels on maps 16 pixels wide)
     int Ho, Wo, OH, OW, M;
     int taps, chunks_per_tap, kt_total;
 };
@@ -1416,13 +1421,20 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->bm = p->Ho % 8 == 0 ? 256 : (p->Ho % 4 == 0 ? 128 : 64);
         p->mtiles = (p->M + p->bm - 1) / p->bm;
     }
-    const int th = p->bm / 32;
+    int th = p->bm / 32;
+    p->tw = 32;
     p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
+    // emulation kernels also take maps 16 pixels wide: 16 x 8 pixel tiles (two image rows per 32-row MFMA block), 128 columns
+    if (!p->halo && (d->flags & RNR_CONV_F32_EMU_ANY) && p->Wo % 32 != 0 && p->Wo % 16 == 0 && p->Ho % 8 == 0) {
+        p->tw = 16; p->cfg = 2; p->bm = 128; p->bn = 128; th = 8;
+        p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+        p->halo = 1;
+    }
     // the halo kernels address a view with 32-bit element offsets
     const long view_elems = (long)H * W * (d->c_in0_pad > d->c_in1_pad ? d->c_in0_pad : d->c_in1_pad);
     if (view_elems >= (1L << 30)) p->halo = 0;
     if (p->halo) {
-        p->mtiles = N * (p->Ho / th) * (p->Wo / 32);
+        p->mtiles = N * (p->Ho / th) * (p->Wo / p->tw);
         if (p->cfg == 1) { p->bn = 80; p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn; }
     }
     const long tiles = (long)p->mtiles * p->ntiles * p->par;
@@ -1442,7 +1454,8 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
 
 template <int FMT, int KIND>
 static void launch_halo_emu(const ConvPlan& pl, const dim3 grid, const ConvParams& P, hipStream_t st) {
-    if (KIND == 1) {        // make_plan forces the 128-column config; rows per tile by what divides the map
+    if (pl.tw == 16) launch_halo_emu_cfg<FMT, KIND, 2, 2, 2, 2, 16>(grid, P, st);       // 16 x 8 pixel tiles, 128 columns
+    else if (KIND == 1) {        // make_plan forces the 128-column config; rows per tile by what divides the map
         if (pl.bm == 256) launch_halo_emu_cfg<FMT, 1, 2, 2, 4, 2>(grid, P, st);
         else if (pl.bm == 128) launch_halo_emu_cfg<FMT, 1, 2, 2, 2, 2>(grid, P, st);
         else launch_halo_emu_cfg<FMT, 1, 2, 2, 1, 2>(grid, P, st);
@@ -1539,7 +1552,7 @@ extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int
     if (!d || num_views <= 0 || d->kind != RNR_CONV3x3_REFLECT) return 0;
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
-    return (pl.halo && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
+    return (pl.halo && pl.tw == 32 && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
 }
 
 extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha, uint8_t* tile_mask, int num_views,

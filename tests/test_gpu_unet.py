@@ -143,7 +143,13 @@ EMU_CASES = [
     (1, 2, 8, 64, [32], 64),           # 4x4 s2, output 4 rows high: 128-row tiles (per-phase halo 5 x 33)
     (1, 1, 4, 128, [48], 128),         # 4x4 s2, output 2 rows high: 64-row tiles, three chunks x four phases
     (1, 1, 512, 512, [16], 128),       # 4x4 s2 at full width: reflection on all four borders, 256-row tiles
-    (0, 1, 16, 16, [64, 64], 128),     # map narrower than 32 px: not covered, falls back to the fp32 kernel from the same buffer
+    (0, 1, 16, 16, [64, 64], 128),     # map 16 px wide: 16 x 8 pixel tiles (two image rows per MFMA row block), skip concat
+    (0, 2, 16, 16, [512], 512),        # 16 px wide, 32 chunks: split-K, four column tiles, two views
+    (1, 2, 32, 32, [64], 128),         # 4x4 s2 onto a 16 x 16 map (per-phase halo 17 x 9)
+    (2, 1, 16, 16, [128], 64),         # transposed conv from a 16 x 16 map
+    (2, 3, 16, 16, [512, 512], 512),   # the U-Net's layer-12/14 shape class at 16 x 16, three views
+    (0, 1, 8, 16, [32], 32),           # 16 wide but only 8 rows: exactly one tile
+    (0, 1, 8, 8, [32], 32),            # narrower than 16 px: not covered, falls back to the fp32 kernel from the same buffer
 ]
 
 
