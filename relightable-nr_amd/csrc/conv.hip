@@ -371,10 +371,13 @@ conv_mfma_kernel(const ConvParams P) {
 // stored to the alternate LDS buffer after them; ONE barrier per 16-channel chunk (round 1 staged weight tiles by
 // LDS-DMA and needed a barrier per tap).
 // ------------------------------------------------------------------------------------------------
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW>
 __global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
-    constexpr int TW = 32, TH = WAVES_M * WM;
+    // TW = 32: a 32-row MFMA block is one image row of the tile; TW = 16 (maps 16 pixels wide): two image rows
+    static_assert(TW == 32 || (TW == 16 && !R16), "tile width");
+    constexpr int RPB = 32 / TW;                           // image rows per MFMA row block
+    constexpr int TH = WAVES_M * WM * RPB;
     // R16 = 1 adds a 16-column remainder tile per wave on v_mfma_f32_16x16x4_f32 (same FLOP rate): Cout = 78 runs as
     // 64 + 16 = 80 columns instead of 96.
     constexpr int WCOLS = WN * 32 + R16 * 16;
@@ -525,9 +528,9 @@ conv_halo_kernel(const ConvParams P) {
     for (int i = 0; i < (R16 ? 2 * WM : 1); i++) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS bases (floats): plane pair of this lane's k parity, its pixel / column, the wave's rows
-    const int wrow = (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0);
-    const float* a_lane = As + ((2 * h) * HP + wrow + l31) * 4;
-    const float* a16_lane = As + (g16 * HP + wrow + l15) * 4;
+    const int wrow = (KIND == 1 ? 2 : 1) * (wave_m * WM * RPB + l31 / TW) * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const float* a_lane = As + ((2 * h) * HP + wrow + l31 % TW) * 4;
+    const float* a16_lane = As + (g16 * HP + (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0) + l15) * 4;   // R16: TW = 32 only
 
     if (c_begin < c_end) {
         const ChunkSrc cs = chunk_src(c_begin);
@@ -566,7 +569,7 @@ conv_halo_kernel(const ConvParams P) {
             if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
             else if (KIND == 1) aoff = (t >> 2) * HWD + ((t & 3) & 1) * (HWD / 2) + ((t & 3) >> 1);
             else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
-            constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * HWD;      // halo pixels between consecutive output rows
+            constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * RPB * HWD;      // halo pixels between consecutive MFMA row blocks
             const float* a_s = a_lane + abuf * ACH + aoff * 4;
             const BRegs& bt = breg[t & 1];
 #pragma unroll
@@ -617,10 +620,11 @@ conv_halo_kernel(const ConvParams P) {
     float* out = P.out + (size_t)split * P.slab_stride;
 #pragma unroll
     for (int i = 0; i < WM; i++) {
-        const int y = y0 + wave_m * WM + i;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
-            const int x = x0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int pb = (g & 3) + 8 * (g >> 2) + 4 * h;          // pixel of the 32-row block this accumulator element holds
+            const int y = y0 + (wave_m * WM + i) * RPB + pb / TW;
+            const int x = x0 + pb % TW;
             const size_t off = (KIND == 2)
                 ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
                 : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
@@ -1129,10 +1133,10 @@ static int balanced_slots(long tiles, int max_slots) {
     return best;
 }
 
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16>
+template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW = 32>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
-    constexpr int TH = WAVES_M * WM, BN = WAVES_N * (WN * 32 + R16 * 16);
-    constexpr int HP = (KIND == 1 ? 66 : 34) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
+    constexpr int TH = WAVES_M * WM * (32 / TW), BN = WAVES_N * (WN * 32 + R16 * 16);
+    constexpr int HP = (KIND == 1 ? 2 * TW + 2 : TW + 2) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
     constexpr size_t lds_halo = (size_t)((KIND == 1 ? 1 : 2) * BK * HP) * sizeof(float);
     constexpr size_t lds_red = (size_t)(WAVES_M * BN * 2) * sizeof(float);         // statistics reduction of the epilogue
     constexpr size_t lds_min = lds_halo > lds_red ? lds_halo : lds_red;
@@ -1144,11 +1148,11 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
     const size_t lds = slots < lds_slots ? (size_t)(160 * 1024 / slots) & ~(size_t)255 : lds_min;
     static size_t attr_set = 0;
     if (attr_set < lds) {    // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16, TW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = lds;
     }
-    hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16>), grid, dim3(CTHREADS), lds, st, P);
+    hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16, TW>), grid, dim3(CTHREADS), lds, st, P);
 }
 
 // out[m,c] = sum_s slab[s][m,c]; statistics per view.  One float4 of one output row per thread (16 rows x 64 columns
@@ -1375,7 +1379,7 @@ struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
-    int tw;         // pixel-tile width of the halo plan: 32, or 16 (emulation kernels on maps 16 pixels wide)
+    int tw;         // pixel-tile width of the halo plan: 32, or 16 (maps 16 pixels wide)
     int Ho, Wo, OH, OW, M;
     int taps, chunks_per_tap, kt_total;
 };
@@ -1424,8 +1428,8 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     int th = p->bm / 32;
     p->tw = 32;
     p->halo = (p->Wo % 32 == 0 && p->Ho % th == 0 && p->Ho >= th) ? 1 : 0;
-    // emulation kernels also take maps 16 pixels wide: 16 x 8 pixel tiles (two image rows per 32-row MFMA block), 128 columns
-    if (!p->halo && (d->flags & RNR_CONV_F32_EMU_ANY) && p->Wo % 32 != 0 && p->Wo % 16 == 0 && p->Ho % 8 == 0) {
+    // maps 16 pixels wide: 16 x 8 pixel tiles (two image rows per 32-row MFMA block), 128 columns
+    if (!p->halo && p->Wo % 32 != 0 && p->Wo % 16 == 0 && p->Ho % 8 == 0) {
         p->tw = 16; p->cfg = 2; p->bm = 128; p->bn = 128; th = 8;
         p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
         p->halo = 1;
@@ -1469,7 +1473,8 @@ static void launch_halo_emu(const ConvPlan& pl, const dim3 grid, const ConvParam
 template <int KIND>
 static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
     const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
-    if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
+    if (pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 2, 2, 0, 16>(grid, P, st);       // 16 x 8 pixel tiles, 128 columns
+    else if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
     else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 2, 1>(grid, P, st);      // 256 x 80
     else if (pl.bm == 256 && KIND != 1) launch_halo_cfg<KIND == 1 ? 0 : KIND, 2, 2, 4, 2, 0>(grid, P, st);
     else launch_halo_cfg<KIND, 2, 2, 2, 2, 0>(grid, P, st);

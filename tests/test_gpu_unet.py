@@ -97,6 +97,13 @@ CASES = [
     (2, 1, 32, 32, [64, 64], 64),      # transposed conv halo kernel, 32x8 tiles, concat
     (2, 2, 32, 64, [128], 128),        # transposed conv halo kernel, 32x4 tiles
     (2, 1, 8, 32, [256], 78),          # transposed conv halo, 256x96 config, split-K
+    (0, 1, 16, 16, [64, 64], 128),     # map 16 px wide: halo kernel on 16 x 8 pixel tiles (two image rows per MFMA row block)
+    (0, 2, 16, 16, [512], 512),        # 16 px wide, split-K, four column tiles, two views
+    (1, 1, 32, 32, [512], 512),        # the U-Net's layer 11: 4x4 s2 onto a 16 x 16 map
+    (1, 2, 32, 32, [64], 96),          # the same with a ragged column tile
+    (2, 3, 16, 16, [512], 512),        # the U-Net's layer 12: transposed conv from a 16 x 16 map, three views
+    (2, 1, 16, 16, [128, 64], 64),     # transposed conv, concat, 64 columns on the 128-column tile
+    (0, 1, 8, 16, [32], 32),           # 16 wide, 8 rows: exactly one tile
     (0, 1, 512, 512, [16], 128),       # enough tiles for the 256x128 fp32 config (two waves per SIMD)
     (2, 1, 256, 256, [16, 16], 128),   # the same for the transposed conv, concat input
 ]
