@@ -238,7 +238,7 @@ typedef struct rnr_conv_desc {
 /* fp32 emulation on the bf16 matrix cores: every operand is split exactly into three bf16 terms and the six leading
  * partial products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error of the order of fp32's own rounding,
  * 2.7x fewer MFMA cycles).  Must be set both when packing the weights and when convolving; layers it does not cover
- * (maps narrower than 32 pixels) run the fp32 MFMA kernels from the same buffer.  Range: finite operands below
+ * (maps narrower than 16 pixels or of odd shape) run the fp32 MFMA kernels from the same buffer.  Range: finite operands below
  * 2^127 (the leading bf16 term of a larger value rounds to infinity); residual terms in fp32's subnormal range are
  * flushed, which only costs precision below 1e-38. */
 #define RNR_CONV_F32_EMU_BF16X6 2

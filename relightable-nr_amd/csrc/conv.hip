@@ -16,7 +16,7 @@
 //   * epilogue  : per-view per-channel sum / sum-of-squares of the raw output (wave shuffles -> LDS ->
 //                 one fp64 atomic per channel per workgroup) for the next BatchNorm's batch statistics.
 //
-// Kernels: conv_halo_kernel (LDS-halo tiles, exact fp32: every map >= 32 px wide), conv_mfma_kernel (tap-by-tap gather:
+// Kernels: conv_halo_kernel (LDS-halo tiles, exact fp32: every map whose width is a multiple of 32, or 16), conv_mfma_kernel (tap-by-tap gather:
 // the small maps), conv_halo_emu_kernel (opt-in: fp32 emulated on the 16-bit matrix cores, RNR_CONV_F32_EMU_BF16X6 / _F16X3).
 // make_plan() picks the kernel, the tile shape (256x64, 256x80, 128x128 or 256x128 rows x columns) and the split-K depth.
 #include "rnr_internal.h"
@@ -353,7 +353,7 @@ conv_mfma_kernel(const ConvParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-halo kernels (maps whose output is at least 32 pixels wide).
+// LDS-halo kernels (maps whose output width is a multiple of 32 pixels, or 16 pixels wide).
 //
 // A workgroup owns a 32 x TH tile of output pixels (TH = 8 or 4).  For every 16-channel chunk it stages the input
 // HALO of that tile once in LDS — reflection padding (or the zero border of the transposed conv), the producer's
