@@ -360,8 +360,7 @@ conv_mfma_kernel(const ConvParams P) {
 // BatchNorm/bias/activation and the skip concat are applied on the way in — and runs ALL taps of the chunk from it.
 // For a tap the MFMA A operand of output row y, lane x is one halo element at a lane-consecutive LDS address:
 //   KIND 0  3x3 s1          halo (TH+2) x 34,   element (y+ky, x+kx)                       9 taps
-//   KIND 1  4x4 s2          halo (2TH+2) x 66,  element (2y+ky, 2x+kx); columns are stored de-interleaved
-//                           (even | odd) so that the stride-2 access stays conflict-free    16 taps
+//   KIND 1  4x4 s2          per input parity phase: halo (TH+1) x 33 of that phase, element (y+a, x+b)   4 x 4 taps
 //   KIND 2  convT 4x4 s2    halo (TH+2) x 34 of the INPUT, zero outside; one output parity class per workgroup,
 //                           element (y+oy(ty), x+ox(tx))                                   4 taps
 // Versus the tap-by-tap gather of conv_mfma_kernel the L2->LDS traffic, the global-load / ds_write instruction count
@@ -372,7 +371,7 @@ conv_mfma_kernel(const ConvParams P) {
 // LDS-DMA and needed a barrier per tap).
 // ------------------------------------------------------------------------------------------------
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW>
-__global__ void __launch_bounds__(CTHREADS, (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
+__global__ void __launch_bounds__(CTHREADS, (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
     // TW = 32: a 32-row MFMA block is one image row of the tile; TW = 16 (maps 16 pixels wide): two image rows
     static_assert(TW == 32 || (TW == 16 && !R16), "tile width");
@@ -382,17 +381,19 @@ conv_halo_kernel(const ConvParams P) {
     // 64 + 16 = 80 columns instead of 96.
     constexpr int WCOLS = WN * 32 + R16 * 16;
     constexpr int BN = WAVES_N * WCOLS;
-    constexpr int TAPS = KIND == 0 ? 9 : (KIND == 1 ? 16 : 4);
-    constexpr int HWD = KIND == 1 ? 2 * TW + 2 : TW + 2;   // halo width  34 / 66
-    constexpr int HHT = KIND == 1 ? 2 * TH + 2 : TH + 2;   // halo height
+    // KIND 1 (4x4 stride 2) runs as FOUR stride-1 2x2-tap convolutions, one per input parity phase (py, px): input row
+    // 2y + ky - 1 = 2(y + ty) + py with (ky; ty, py) = (0; -1, 1), (1; 0, 0), (2; 0, 1), (3; 1, 0).  A K step is a
+    // (16-channel chunk, phase) pair whose halo is the (TH+1) x (TW+1) pixels of that phase only (297 pixels for a 32 x 8
+    // tile; the interleaved halo of all 16 taps takes 1188 and fitted LDS only single-buffered with 4-row tiles, r01).
+    constexpr int NPH = KIND == 1 ? 4 : 1;                 // K steps per 16-channel chunk
+    constexpr int TAPS = KIND == 0 ? 9 : 4;                // taps per K step
+    constexpr int HWD = KIND == 1 ? TW + 1 : TW + 2;       // halo width
+    constexpr int HHT = KIND == 1 ? TH + 1 : TH + 2;       // halo height
     constexpr int HP = HWD * HHT;
     constexpr int ASLOTS = HP * 4;                         // float4 slots of one halo chunk (pixel x channel quad)
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
     constexpr int APS = (APT + TAPS - 1) / TAPS;           // halo float4 fetched per pipeline step
-    // The 4x4-s2 halo (660 px) double-buffered would leave room for one workgroup per CU only (MFMA pipe 53 % busy,
-    // profiles/r01_pmc_per_kernel_v4): keep ONE LDS copy, carry the next chunk's halo in registers across the 16 taps
-    // and swap it in between chunks (one extra barrier per chunk) -> two workgroups per CU.
-    constexpr int ABUFS = KIND == 1 ? 1 : 2;
+    constexpr int ABUFS = 2;                               // the halo is double-buffered in LDS
     // LDS image of one 16-channel chunk, for the halo (X = HP pixels) and for the weight tile (X = BN columns):
     //   [4 planes g][X][4 floats e],  channel k of the chunk -> g = 2*(k&1) + (k>>3), e = (k>>1)&3.
     // An MFMA lane (x, h) needs channels k = 2s+h, s = 0..7, of ONE pixel / column: that is planes 2h and 2h+1 at
@@ -427,7 +428,8 @@ conv_halo_kernel(const ConvParams P) {
     // halo slots of this thread: fixed source pixels for the whole K loop.  Slots past the halo fetch a valid address
     // (an earlier slot's) and are never stored; the zero border of the transposed conv is a 0/1 factor.
     const int q = tid & 3;
-    unsigned spix[APT];      // pixel index inside the view
+    unsigned spix[KIND == 1 ? 1 : APT];      // pixel index inside the view (KIND 1: recomputed per phase from siy / six)
+    short siy[KIND == 1 ? APT : 1], six[KIND == 1 ? APT : 1];      // KIND 1: 2 (y0 + hy), 2 (x0 + hx)
     int sdst[APT];           // float index of the (x, z) pair inside a chunk image; the (y, w) pair is 2 planes on
     float smask[KIND == 2 ? APT : 1];
 #pragma unroll
@@ -436,19 +438,18 @@ conv_halo_kernel(const ConvParams P) {
         if (s >= ASLOTS) s -= ASLOTS;
         const int hp = s >> 2;
         const int hy = hp / HWD, hx = hp - hy * HWD;
-        int iy, ix, col = hx;
+        int iy = 0, ix = 0;
+        const int col = hx;
         if (KIND == 0) { iy = reflect1(y0 - 1 + hy, P.H); ix = reflect1(x0 - 1 + hx, P.W); }
-        else if (KIND == 1) {
-            iy = reflect1(2 * y0 - 1 + hy, P.H); ix = reflect1(2 * x0 - 1 + hx, P.W);
-            col = (hx & 1) * (HWD / 2) + (hx >> 1);                 // de-interleave even | odd columns
-        } else {
+        else if (KIND == 1) { siy[j] = (short)(2 * (y0 + hy)); six[j] = (short)(2 * (x0 + hx)); }
+        else {
             iy = y0 - 1 + hy; ix = x0 - 1 + hx;
             const bool inside = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
             smask[j] = inside ? 1.f : 0.f;                          // exactly 0 outside, not act(shift)
             iy = min(max(iy, 0), P.H - 1); ix = min(max(ix, 0), P.W - 1);
         }
         sdst[j] = ((q >> 1) * HP + hy * HWD + col) * 4 + 2 * (q & 1);
-        spix[j] = (unsigned)(iy * P.W + ix);
+        if (KIND != 1) spix[j] = (unsigned)(iy * P.W + ix);
     }
 
     const int nchunks = P.chunks_per_tap;
@@ -460,9 +461,12 @@ conv_halo_kernel(const ConvParams P) {
     // (make_plan keeps H*W*C below 2^30), so a halo fetch is one global_load_dwordx4 v, voff, s[base] and one VALU mad.
     // (buffer loads: resource + scalar offset + one 32-bit lane offset; flat 64-bit addresses make the unrolled tap loop
     // keep a strength-reduced pointer pair per (tap, plane) alive across the chunk loop — registers the kernel lacks)
-    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; float4 sc, sh; };
-    auto chunk_src = [&](int c) {
+    // K steps: step = chunk * NPH + phase
+    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; int phy, phx; float4 sc, sh; };
+    auto chunk_src = [&](int step) {
         ChunkSrc cs;
+        const int c = step / NPH;
+        cs.phy = (step % NPH) >> 1; cs.phx = (step % NPH) & 1;
         const int s = c < P.chunks0 ? 0 : 1;
         const int cc = (c - (s ? P.chunks0 : 0)) * BK;
         cs.C = (unsigned)P.src_c[s];
@@ -477,7 +481,10 @@ conv_halo_kernel(const ConvParams P) {
         return cs;
     };
     auto load_a = [&](const ChunkSrc& cs, int j) {
-        const unsigned voff = (spix[j] * cs.C + 4u * (unsigned)q) * 4u;
+        unsigned pixel;
+        if (KIND == 1) pixel = (unsigned)(reflect1(siy[j] - cs.phy, P.H) * P.W + reflect1(six[j] - cs.phx, P.W));
+        else pixel = spix[j];
+        const unsigned voff = (pixel * cs.C + 4u * (unsigned)q) * 4u;
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, (int)voff, (int)cs.soff, 0));
     };
     auto store_a = [&](const ChunkSrc& cs, float4 v, int j, int buf) {
@@ -504,8 +511,14 @@ conv_halo_kernel(const ConvParams P) {
     const int g16 = (kq & 1) * 2 + (kq >> 1);
     const unsigned bvoff16 = ((unsigned)g16 * (unsigned)P.wstride + (unsigned)(n0 + wn0 + WN * 32 + l15)) * 16u;
     struct BRegs { floatx4 b[2][WN]; floatx4 b16; };
-    auto load_b = [&](BRegs& dst, int c, int t) {
-        const unsigned soff = (unsigned)((par * TAPS + t) * nchunks + c) * tile_bytes;      // wave-uniform
+    auto load_b = [&](BRegs& dst, int step, int t) {
+        const int c = step / NPH;
+        int tap = par * TAPS + t;
+        if (KIND == 1) {    // tap (a, b) of phase (py, px) is kernel element ky = py ? 2a : 1 + 2a (same for kx)
+            const int phy = (step % NPH) >> 1, phx = (step % NPH) & 1, ta = t >> 1, tb = t & 1;
+            tap = (phy ? 2 * ta : 1 + 2 * ta) * 4 + (phx ? 2 * tb : 1 + 2 * tb);
+        }
+        const unsigned soff = (unsigned)(tap * nchunks + c) * tile_bytes;      // wave-uniform
 #pragma unroll
         for (int sg = 0; sg < 2; sg++)
 #pragma unroll
@@ -528,24 +541,24 @@ conv_halo_kernel(const ConvParams P) {
     for (int i = 0; i < (R16 ? 2 * WM : 1); i++) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS bases (floats): plane pair of this lane's k parity, its pixel / column, the wave's rows
-    const int wrow = (KIND == 1 ? 2 : 1) * (wave_m * WM * RPB + l31 / TW) * HWD + (KIND == 2 ? py * HWD + px : 0);
+    const int wrow = (wave_m * WM * RPB + l31 / TW) * HWD + (KIND == 2 ? py * HWD + px : 0);
     const float* a_lane = As + ((2 * h) * HP + wrow + l31 % TW) * 4;
-    const float* a16_lane = As + (g16 * HP + (KIND == 1 ? 2 : 1) * wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0) + l15) * 4;   // R16: TW = 32 only
+    const float* a16_lane = As + (g16 * HP + wave_m * WM * HWD + (KIND == 2 ? py * HWD + px : 0) + l15) * 4;   // R16: TW = 32 only
 
     if (c_begin < c_end) {
-        const ChunkSrc cs = chunk_src(c_begin);
+        const ChunkSrc cs = chunk_src(c_begin * NPH);
 #pragma unroll
         for (int j = 0; j < APT; j++)
             if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j, 0);
     }
+    const int s_begin = c_begin * NPH, s_end = c_end * NPH;
     BRegs breg[2];
-    if (c_begin < c_end) load_b(breg[0], c_begin, 0);
+    if (s_begin < s_end) load_b(breg[0], s_begin, 0);
     __syncthreads();
-    for (int c = c_begin; c < c_end; c++) {
-        const int abuf = ABUFS == 2 ? ((c - c_begin) & 1) : 0;
-        const bool next_chunk = c + 1 < c_end;
+    for (int c = s_begin; c < s_end; c++) {                     // c = K step (chunk, phase)
+        const int abuf = (c - s_begin) & 1;
+        const bool next_chunk = c + 1 < s_end;
         ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
-        float4 av_all[ABUFS == 1 ? APT : 1];
 #pragma unroll
         for (int t = 0; t < TAPS; t++) {
             // the next tap's (or the next chunk's first) weights are requested before this tap's MFMAs
@@ -557,19 +570,16 @@ conv_halo_kernel(const ConvParams P) {
                 const int j = t * APS + u;
                 av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
-                if (next_chunk && j < APT) {
-                    av[u] = load_a(csn, j);
-                    if (ABUFS == 1) av_all[j] = av[u];
-                }
+                if (next_chunk && j < APT) av[u] = load_a(csn, j);
 #endif
             }
             // halo pixel of output row (wave_m*WM + i), lane x for this tap: compile-time part here, the parity shift
             // of the transposed conv and the wave's row block are in a_lane
             int aoff;
             if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
-            else if (KIND == 1) aoff = (t >> 2) * HWD + ((t & 3) & 1) * (HWD / 2) + ((t & 3) >> 1);
+            else if (KIND == 1) aoff = (t >> 1) * HWD + (t & 1);
             else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
-            constexpr int ROWSTEP = (KIND == 1 ? 2 : 1) * RPB * HWD;      // halo pixels between consecutive MFMA row blocks
+            constexpr int ROWSTEP = RPB * HWD;      // halo pixels between consecutive MFMA row blocks
             const float* a_s = a_lane + abuf * ACH + aoff * 4;
             const BRegs& bt = breg[t & 1];
 #pragma unroll
@@ -597,23 +607,15 @@ conv_halo_kernel(const ConvParams P) {
                 }
             }
 #if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
-            if (ABUFS == 2) {
 #pragma unroll
-                for (int u = 0; u < APS; u++) {
-                    const int j = t * APS + u;
-                    if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[u], j, abuf ^ 1);
-                }
+            for (int u = 0; u < APS; u++) {
+                const int j = t * APS + u;
+                if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[u], j, abuf ^ 1);
             }
 #endif
         }
         if (TAPS & 1) breg[0] = breg[1];
-        __syncthreads();                    // everybody is done reading this chunk's halo; the next one (ABUFS == 2) is complete
-        if (ABUFS == 1 && next_chunk) {     // single LDS copy: swap the register-parked halo in
-#pragma unroll
-            for (int j = 0; j < APT; j++)
-                if (tid + CTHREADS * j < ASLOTS) store_a(csn, av_all[j], j, 0);
-            __syncthreads();
-        }
+        __syncthreads();                    // everybody is done reading this step's halo; the next one is complete
     }
 
     // ---- epilogue ----
@@ -1136,12 +1138,12 @@ static int balanced_slots(long tiles, int max_slots) {
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW = 32>
 static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st) {
     constexpr int TH = WAVES_M * WM * (32 / TW), BN = WAVES_N * (WN * 32 + R16 * 16);
-    constexpr int HP = (KIND == 1 ? 2 * TW + 2 : TW + 2) * (KIND == 1 ? 2 * TH + 2 : TH + 2);
-    constexpr size_t lds_halo = (size_t)((KIND == 1 ? 1 : 2) * BK * HP) * sizeof(float);
+    constexpr int HP = (KIND == 1 ? TW + 1 : TW + 2) * (KIND == 1 ? TH + 1 : TH + 2);
+    constexpr size_t lds_halo = (size_t)(2 * BK * HP) * sizeof(float);
     constexpr size_t lds_red = (size_t)(WAVES_M * BN * 2) * sizeof(float);         // statistics reduction of the epilogue
     constexpr size_t lds_min = lds_halo > lds_red ? lds_halo : lds_red;
     // workgroups per CU the registers allow (the kernel's __launch_bounds__) and LDS allows
-    constexpr int nat = (KIND != 1 && WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1);
+    constexpr int nat = (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1);
     constexpr int lds_slots = (int)((160 * 1024) / lds_min);
     const int slots = balanced_slots((long)grid.x, nat < lds_slots ? nat : lds_slots);
     // fewer co-resident workgroups are requested by padding the dynamic LDS allocation
@@ -1399,8 +1401,8 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     else { p->cfg = 2; p->bm = 128; p->bn = 128; }
     p->mtiles = (p->M + p->bm - 1) / p->bm;
     p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
-    // halo kernels: 32 x th tiles of the GEMM row space, all tile pixels inside the map.  The 4x4-s2 halo only fits
-    // LDS with th = 4 (128-row tiles).
+    // halo kernels: 32 x th tiles of the GEMM row space, all tile pixels inside the map.  The 4x4-s2 convolution runs
+    // on the 128-column configuration.
     if (d->kind == RNR_CONV4x4S2_REFLECT && p->cfg != 2 && p->Wo % 32 == 0 && p->Ho % 4 == 0) {
         p->cfg = 2; p->bm = 128; p->bn = 128;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
@@ -1414,7 +1416,7 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     }
     // exact-fp32 kernels: 256 x 128 tiles (two waves per SIMD, half the weight traffic and barriers per MFMA) once there
     // are enough of them to fill the 256 CUs twice over; below that the 128 x 128 tiles keep more CUs busy
-    if (!(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && d->kind != RNR_CONV4x4S2_REFLECT && p->Wo % 32 == 0 &&
+    if (!(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && p->Wo % 32 == 0 &&
         p->Ho % 8 == 0 && (long)(p->M / 256) * p->ntiles * p->par >= RNR_NATIVE_BIG_MIN) {
         p->bm = 256;
         p->mtiles = (p->M + p->bm - 1) / p->bm;
@@ -1476,7 +1478,7 @@ static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st)
     if (pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 2, 2, 0, 16>(grid, P, st);       // 16 x 8 pixel tiles, 128 columns
     else if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
     else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 2, 1>(grid, P, st);      // 256 x 80
-    else if (pl.bm == 256 && KIND != 1) launch_halo_cfg<KIND == 1 ? 0 : KIND, 2, 2, 4, 2, 0>(grid, P, st);
+    else if (pl.bm == 256) launch_halo_cfg<KIND, 2, 2, 4, 2, 0>(grid, P, st);
     else launch_halo_cfg<KIND, 2, 2, 2, 2, 0>(grid, P, st);
 }
 
