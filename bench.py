@@ -385,7 +385,7 @@ def main():
                                   'v_mfma_f32_32x32x16_bf16'),
                     ('f16x3', 3, 'every conv operand split into 2 fp16 terms (22 significand bits, weights pre-scaled per layer by '
                                  'a power of two), 3 partial products accumulated in fp32 on v_mfma_f32_32x32x16_f16; error vs '
-                                 'float64 at or below the exact-fp32 kernels on all 22 layer shapes (profiles/r02_emu_layer_table.md)')]:
+                                 'float64 0.32-0.87x the exact-fp32 kernels on 21 of 22 layer shapes, 1.01x on the last (profiles/r02_emu_layer_table.md)')]:
                 pe = RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'],
                                  sc['pivots_diff'], None, nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'],
                                  sh_lmax=10, skip_background_tiles=False, precision=prec)
