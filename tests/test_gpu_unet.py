@@ -227,6 +227,52 @@ def test_emulation_halo_swap_stress(fmt):
         assert (emu - nat).abs().max() < 1e-4, rep
 
 
+def _random_conv_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        kind = int(rng.randint(0, 3))
+        N = int(rng.randint(1, 4))
+        # output-space width: 16, 32, 48, 64, 96 ... exercises the 16-wide tiles, the 32-wide tiles and the gather kernel (48)
+        wo = int(rng.choice([8, 16, 16, 32, 32, 48, 64, 96]))
+        ho = int(rng.choice([2, 4, 8, 12, 16, 24, 32, 40]))
+        H, W = (ho, wo) if kind != 1 else (2 * ho, 2 * wo)
+        two = rng.rand() < 0.4
+        cins = [int(rng.choice([3, 16, 20, 32, 48, 64, 100]))] + ([int(rng.choice([16, 32, 64]))] if two else [])
+        c_out = int(rng.choice([3, 16, 30, 64, 78, 96, 128, 160, 256]))
+        cases.append((kind, N, H, W, cins, c_out))
+    return cases
+
+
+@pytest.mark.parametrize('fmt', ['f32', 'bf16x6', 'f16x3'])
+def test_conv_random_shapes(fmt):
+    """Seeded sweep over layer shapes (all three kinds, 1-3 views, ragged channel counts, map widths that select the 32-wide
+    halo tiles, the 16-wide ones, the per-phase stride-2 scheme and the gather kernel, with and without skip concat):
+    every conv path must agree with a float64 convolution; catches tile / index arithmetic slips the fixed cases miss."""
+    from rnr_amd import _lib
+    flag = _lib.EMU_FLAGS[fmt]
+    for ci, (kind, N, H, W, cins, c_out) in enumerate(_random_conv_cases(36, 2026)):
+        g = torch.Generator().manual_seed(1000 + ci)
+        srcs = []
+        for j, C in enumerate(cins):
+            raw = torch.randn(N, C, H, W, generator=g)
+            sc = torch.rand(N, C, generator=g) + 0.5 if j == 0 else None
+            sh = torch.randn(N, C, generator=g) * 0.3
+            srcs.append((raw, sc, sh, 1 if j == 0 else 2))
+        cin = sum(cins)
+        k = 4 if kind else 3
+        w = (torch.randn(cin, c_out, 4, 4, generator=g) if kind == 2 else torch.randn(c_out, cin, k, k, generator=g)) / (cin * k * k) ** 0.5
+        out, stats = run_conv(kind, srcs, w, c_out, N, H, W, flags=flag)
+        ref = ref_conv(kind, srcs, w).permute(0, 2, 3, 1)
+        got = out[..., :c_out].double()
+        tag = (fmt, ci, kind, N, H, W, cins, c_out)
+        assert torch.isfinite(out).all(), tag
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 1e-4 * scale, (tag, float((got - ref).abs().max()), scale)
+        assert float(out[..., c_out:].abs().max() if out.shape[-1] > c_out else 0.0) == 0.0, tag
+        assert torch.allclose(stats[:, :c_out, 1], (ref * ref).sum(dim=(1, 2)), rtol=1e-4), tag
+
+
 def _sd(g):
     return {k[3:]: T(g[k]) for k in g.files if k.startswith('sd:')}
 
