@@ -38,6 +38,9 @@ constexpr int CTHREADS = 256;
 #ifndef RNR_NATIVE_BIG_MIN
 #define RNR_NATIVE_BIG_MIN 512     // measured: 512 >= 1024, 2048 at 8, 4, 2 views per launch, all equal at 1
 #endif
+#ifndef RNR_HALO_HDIST
+#define RNR_HALO_HDIST 2   // conv_halo_kernel: taps between the fetch of a halo slice and its store to LDS
+#endif
 #ifndef RNR_HALO_WAVES
 #define RNR_HALO_WAVES 3    // waves per SIMD the halo kernels are register-bounded for (4 would spill and exceed LDS anyway)
 #endif
@@ -370,6 +373,43 @@ conv_mfma_kernel(const ConvParams P) {
 // stored to the alternate LDS buffer after them; ONE barrier per 16-channel chunk (round 1 staged weight tiles by
 // LDS-DMA and needed a barrier per tap).
 // ------------------------------------------------------------------------------------------------
+// Epilogue of the halo kernels: the wave's accumulator tiles go to the NHWC output as buffer stores.  The address of
+// element (row block i, register g, column block j) splits into a workgroup-uniform 64-bit base (the resource), a
+// wave-uniform 32-bit offset per (i, g) (SGPR) and ONE per-lane 32-bit offset per column block, computed once: a store
+// is one instruction (no 64-bit VALU address arithmetic, no branch); lanes of padding columns beyond c_out_pad get an
+// out-of-range offset and the hardware drops their store.
+// Accumulator layout of v_mfma_f32_32x32x*: lane (l31, h), register g holds row (g & 3) + 8 (g >> 2) + 4 h, column l31.
+template <int KIND, int WM, int WN, int TW>
+__device__ __forceinline__ void store_acc_tiles(const ConvParams& P, float* out, const floatx16 (&acc)[WM][WN], int n, int y0,
+                                                int x0, int py, int px, int wave_m, int n0, int wn0, int l31, int h) {
+    constexpr int RPB = 32 / TW, XM = KIND == 2 ? 2 : 1;       // transposed conv: this parity class writes every other pixel
+    const int wm = __builtin_amdgcn_readfirstlane(wave_m);
+    const int Y00 = XM * y0 + (KIND == 2 ? py : 0), X00 = XM * x0 + (KIND == 2 ? px : 0);
+    float* base = out + (((size_t)n * P.OH + Y00) * P.OW + X00) * P.c_out_pad + n0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x27000);
+    const unsigned cp4 = (unsigned)P.c_out_pad * 4u;
+    unsigned voff[WN];
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+        const int colw = wn0 + 32 * j + l31;
+        voff[j] = (n0 + colw < P.c_out_pad) ? (unsigned)(XM * 4 * h) * cp4 + (unsigned)colw * 4u : 0x7fffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int pb0 = (g & 3) + 8 * (g >> 2);             // + 4 h: lane part (never crosses an image row of the tile)
+            const int yrel = (wm * WM + i) * RPB + pb0 / TW, xrel = pb0 % TW;
+            const unsigned soff = (unsigned)(XM * (yrel * P.OW + xrel)) * cp4;
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                const float v = acc[i][j][g];       // (bit_cast straight from the vector element stores element 0: compiler bug)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (int)voff[j], (int)soff, 0);
+            }
+        }
+    }
+}
+
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW>
 __global__ void __launch_bounds__(CTHREADS, (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
 conv_halo_kernel(const ConvParams P) {
@@ -559,12 +599,13 @@ conv_halo_kernel(const ConvParams P) {
         const int abuf = (c - s_begin) & 1;
         const bool next_chunk = c + 1 < s_end;
         ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
+        float4 avr[2][APS];                 // halo slices in flight: fetched during tap t, stored after tap t + HDIST - 1
 #pragma unroll
         for (int t = 0; t < TAPS; t++) {
             // the next tap's (or the next chunk's first) weights are requested before this tap's MFMAs
             if (t < TAPS - 1) load_b(breg[(t + 1) & 1], c, t + 1);
             else if (next_chunk) load_b(breg[TAPS & 1], c + 1, 0);
-            float4 av[APS];
+            float4 (&av)[APS] = avr[t & 1];
 #pragma unroll
             for (int u = 0; u < APS; u++) {
                 const int j = t * APS + u;
@@ -607,36 +648,33 @@ conv_halo_kernel(const ConvParams P) {
                 }
             }
 #if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
+            // the slice fetched HDIST - 1 taps ago goes to LDS now (HDIST = 2: two taps of MFMAs cover the HBM latency)
+            const int ts = t - (RNR_HALO_HDIST - 1);
+            if (ts >= 0) {
 #pragma unroll
-            for (int u = 0; u < APS; u++) {
-                const int j = t * APS + u;
-                if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[u], j, abuf ^ 1);
+                for (int u = 0; u < APS; u++) {
+                    const int j = ts * APS + u;
+                    if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, avr[ts & 1][u], j, abuf ^ 1);
+                }
             }
 #endif
         }
+#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
+        if (RNR_HALO_HDIST == 2 && (TAPS - 1) * APS < APT) {        // the slice of the last tap
+#pragma unroll
+            for (int u = 0; u < APS; u++) {
+                const int j = (TAPS - 1) * APS + u;
+                if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, avr[(TAPS - 1) & 1][u], j, abuf ^ 1);
+            }
+        }
+#endif
         if (TAPS & 1) breg[0] = breg[1];
         __syncthreads();                    // everybody is done reading this step's halo; the next one is complete
     }
 
     // ---- epilogue ----
     float* out = P.out + (size_t)split * P.slab_stride;
-#pragma unroll
-    for (int i = 0; i < WM; i++) {
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int pb = (g & 3) + 8 * (g >> 2) + 4 * h;          // pixel of the 32-row block this accumulator element holds
-            const int y = y0 + (wave_m * WM + i) * RPB + pb / TW;
-            const int x = x0 + pb % TW;
-            const size_t off = (KIND == 2)
-                ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
-                : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
-#pragma unroll
-            for (int j = 0; j < WN; j++) {
-                const int col = n0 + wn0 + 32 * j + l31;
-                if (col < P.c_out_pad) out[off + col] = acc[i][j][g];
-            }
-        }
-    }
+    store_acc_tiles<KIND, WM, WN, TW>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h);
     if (R16) {   // C layout of the 16x16 tiles: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int col = n0 + wn0 + WN * 32 + l15;
 #pragma unroll
@@ -1040,23 +1078,7 @@ conv_halo_emu_kernel(const ConvParams P) {
                 for (int g = 0; g < 16; g++) acc[i][j][g] *= winv;
     }
     float* out = P.out + (size_t)split * P.slab_stride;
-#pragma unroll
-    for (int i = 0; i < WM; i++) {
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int pb = (g & 3) + 8 * (g >> 2) + 4 * h;          // pixel of the 32-row block this accumulator element holds
-            const int y = y0 + (wave_m * WM + i) * RPB + pb / TW;
-            const int x = x0 + pb % TW;
-            const size_t off = (KIND == 2)
-                ? (((size_t)n * P.OH + 2 * y + py) * P.OW + 2 * x + px) * P.c_out_pad
-                : (((size_t)n * P.OH + y) * P.OW + x) * P.c_out_pad;
-#pragma unroll
-            for (int j = 0; j < WN; j++) {
-                const int col = n0 + wn0 + 32 * j + l31;
-                if (col < P.c_out_pad) out[off + col] = acc[i][j][g];
-            }
-        }
-    }
+    store_acc_tiles<KIND, WM, WN, TW>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h);
     if (P.stats && P.splitk == 1) {
         float* red = reinterpret_cast<float*>(As);   // [WAVES_M][BN][2]; LDS is free after the last barrier
 #pragma unroll
