@@ -39,7 +39,7 @@ constexpr int CTHREADS = 256;
 #define RNR_NATIVE_BIG_MIN 512     // measured: 512 >= 1024, 2048 at 8, 4, 2 views per launch, all equal at 1
 #endif
 #ifndef RNR_HALO_HDIST
-#define RNR_HALO_HDIST 2   // conv_halo_kernel: taps between the fetch of a halo slice and its store to LDS
+#define RNR_HALO_HDIST 2   // conv_halo_kernel: taps between the fetch of a halo slice and its store to LDS (transposed conv: 1)
 #endif
 #ifndef RNR_HALO_WAVES
 #define RNR_HALO_WAVES 3    // waves per SIMD the halo kernels are register-bounded for (4 would spill and exceed LDS anyway)
@@ -379,9 +379,10 @@ conv_mfma_kernel(const ConvParams P) {
 // is one instruction (no 64-bit VALU address arithmetic, no branch); lanes of padding columns beyond c_out_pad get an
 // out-of-range offset and the hardware drops their store.
 // Accumulator layout of v_mfma_f32_32x32x*: lane (l31, h), register g holds row (g & 3) + 8 (g >> 2) + 4 h, column l31.
-template <int KIND, int WM, int WN, int TW>
+template <int KIND, int WM, int WN, int TW, bool SCALED = false>
 __device__ __forceinline__ void store_acc_tiles(const ConvParams& P, float* out, const floatx16 (&acc)[WM][WN], int n, int y0,
-                                                int x0, int py, int px, int wave_m, int n0, int wn0, int l31, int h) {
+                                                int x0, int py, int px, int wave_m, int n0, int wn0, int l31, int h,
+                                                float scale = 1.0f) {
     constexpr int RPB = 32 / TW, XM = KIND == 2 ? 2 : 1;       // transposed conv: this parity class writes every other pixel
     const int wm = __builtin_amdgcn_readfirstlane(wave_m);
     const int Y00 = XM * y0 + (KIND == 2 ? py : 0), X00 = XM * x0 + (KIND == 2 ? px : 0);
@@ -403,7 +404,8 @@ __device__ __forceinline__ void store_acc_tiles(const ConvParams& P, float* out,
             const unsigned soff = (unsigned)(XM * (yrel * P.OW + xrel)) * cp4;
 #pragma unroll
             for (int j = 0; j < WN; j++) {
-                const float v = acc[i][j][g];       // (bit_cast straight from the vector element stores element 0: compiler bug)
+                // (bit_cast straight from the vector element stores element 0: compiler bug — go through a scalar)
+                const float v = SCALED ? acc[i][j][g] * scale : acc[i][j][g];
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, (int)voff[j], (int)soff, 0);
             }
         }
@@ -434,6 +436,9 @@ conv_halo_kernel(const ConvParams P) {
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
     constexpr int APS = (APT + TAPS - 1) / TAPS;           // halo float4 fetched per pipeline step
     constexpr int ABUFS = 2;                               // the halo is double-buffered in LDS
+    // two taps of MFMAs between a halo slice's fetch and its store cover the HBM latency (+0.4 %); the transposed conv at
+    // three waves per SIMD has no registers for the second slice (it would spill to scratch)
+    constexpr int HDIST = KIND == 2 ? 1 : RNR_HALO_HDIST;
     // LDS image of one 16-channel chunk, for the halo (X = HP pixels) and for the weight tile (X = BN columns):
     //   [4 planes g][X][4 floats e],  channel k of the chunk -> g = 2*(k&1) + (k>>3), e = (k>>1)&3.
     // An MFMA lane (x, h) needs channels k = 2s+h, s = 0..7, of ONE pixel / column: that is planes 2h and 2h+1 at
@@ -649,7 +654,7 @@ conv_halo_kernel(const ConvParams P) {
             }
 #if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
             // the slice fetched HDIST - 1 taps ago goes to LDS now (HDIST = 2: two taps of MFMAs cover the HBM latency)
-            const int ts = t - (RNR_HALO_HDIST - 1);
+            const int ts = t - (HDIST - 1);
             if (ts >= 0) {
 #pragma unroll
                 for (int u = 0; u < APS; u++) {
@@ -660,7 +665,7 @@ conv_halo_kernel(const ConvParams P) {
 #endif
         }
 #if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
-        if (RNR_HALO_HDIST == 2 && (TAPS - 1) * APS < APT) {        // the slice of the last tap
+        if (HDIST == 2 && (TAPS - 1) * APS < APT) {        // the slice of the last tap
 #pragma unroll
             for (int u = 0; u < APS; u++) {
                 const int j = (TAPS - 1) * APS + u;
@@ -1068,17 +1073,12 @@ conv_halo_emu_kernel(const ConvParams P) {
     }
 
     // ---- epilogue (identical to conv_halo_kernel: same accumulator layout) ----
-    if (FMT == 1) {         // undo the power-of-two weight scale (exact)
-        const float winv = *reinterpret_cast<const float*>(P.weight_emu);
-#pragma unroll
-        for (int i = 0; i < WM; i++)
-#pragma unroll
-            for (int j = 0; j < WN; j++)
-#pragma unroll
-                for (int g = 0; g < 16; g++) acc[i][j][g] *= winv;
-    }
+    // f16x3: undo the power-of-two weight scale — at the store, and on the column sums of the statistics (a power of
+    // two commutes with every fp32 rounding involved, so this equals scaling the accumulators first; scaling all 128 of
+    // them in place made the compiler keep both copies and spill)
+    const float winv = FMT == 1 ? *reinterpret_cast<const float*>(P.weight_emu) : 1.0f;
     float* out = P.out + (size_t)split * P.slab_stride;
-    store_acc_tiles<KIND, WM, WN, TW>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h);
+    store_acc_tiles<KIND, WM, WN, TW, FMT == 1>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h, winv);
     if (P.stats && P.splitk == 1) {
         float* red = reinterpret_cast<float*>(As);   // [WAVES_M][BN][2]; LDS is free after the last barrier
 #pragma unroll
@@ -1092,6 +1092,7 @@ conv_halo_emu_kernel(const ConvParams P) {
                     s1 += v;
                     s2 += v * v;
                 }
+            if (FMT == 1) { s1 *= winv; s2 = (s2 * winv) * winv; }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) {
@@ -1408,6 +1409,11 @@ struct ConvPlan {
     int taps, chunks_per_tap, kt_total;
 };
 
+__global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
 static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     p->taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : (d->kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
     p->par = d->kind == RNR_CONVT4x4S2 ? 4 : 1;
@@ -1642,8 +1648,11 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.tile_mask = tile_mask;
     }
     const size_t out_floats = (size_t)num_views * pl.OH * pl.OW * d->c_out_pad;
-    if (stats && !(d->flags & RNR_CONV_STATS_PREZEROED))
-        RNR_HIP(hipMemsetAsync(stats, 0, (size_t)num_views * d->c_out_pad * 2 * sizeof(double), st));
+    if (stats && !(d->flags & RNR_CONV_STATS_PREZEROED)) {
+        // (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph went stale on replay, raster.hip)
+        const long n = (long)num_views * d->c_out_pad * 2;
+        hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, stats, n);
+    }
     if (pl.splitk > 1) {
         RNR_REQUIRE(workspace && workspace_bytes >= (size_t)pl.splitk * out_floats * sizeof(float),
                     "rnr_conv2d: workspace too small (%zu < %zu)", workspace_bytes,

@@ -637,6 +637,16 @@ static size_t bin_bytes(int batch, int nf, int is) {
 }
 
 // Small trusted faces are resolved face-parallel into P.keys (near >= 0), everything else is binned into the tile lists;
+// Clears the bin counters (zeros) and the per-pixel depth keys (all ones) in one launch.  Not hipMemsetAsync: memset
+// nodes of a captured HIP graph went stale on replay once any other copy / fill had run in between (GPU write fault,
+// scripts/exp_graph2.py raster), kernels replay correctly.
+__global__ void __launch_bounds__(256)
+raster_clear_kernel(uint4* __restrict__ counters, long counter_vec, uint4* __restrict__ keys, long key_vec) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < counter_vec) counters[i] = make_uint4(0u, 0u, 0u, 0u);
+    else if (i - counter_vec < key_vec) keys[i - counter_vec] = make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+
 // fills P.tile_count / P.tile_list / P.keys.
 static int run_binning(char* ws, const float* faces, const float* faces_inv, const FaceBox* boxes, int batch, int nf, int is,
                        RasterParams* P, hipStream_t st) {
@@ -649,11 +659,16 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(
         ws + bin_counter_bytes(batch, is) + align_up((size_t)batch * ntiles * BIN_CAP * sizeof(int), 256) +
         align_up((size_t)batch * nf * sizeof(int), 256));
-    RNR_HIP(hipMemsetAsync(tile_count, 0, (size_t)batch * (ntiles + 1) * sizeof(int), st));
     const long total = (long)batch * nf;
     const bool splat = P->near_ >= 0.0f;            // the key order needs zp > 0, which the near test then guarantees
+    {   // both regions are 256-byte aligned and padded (bin_counter_bytes / key_bytes): whole uint4 stores
+        const long cvec = (long)(bin_counter_bytes(batch, is) / sizeof(uint4));
+        const long kvec = splat ? (long)(key_bytes(batch, is) / sizeof(uint4)) : 0;
+        hipLaunchKernelGGL(raster_clear_kernel, dim3((unsigned)((cvec + kvec + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<uint4*>(tile_count), cvec, reinterpret_cast<uint4*>(keys), kvec);
+        if (int e = check_launch("raster_clear_kernel")) return e;
+    }
     if (splat) {
-        RNR_HIP(hipMemsetAsync(keys, 0xFF, (size_t)batch * is * is * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(splat_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, faces_inv, boxes,
                            keys, wide_count, wide_list, batch, nf, is, P->near_, P->far_);
         if (int e = check_launch("splat_faces_kernel")) return e;

@@ -294,6 +294,44 @@ def test_emulation_frame(fmt):
     assert (emu - f32).abs().max() < 2e-4, (emu - f32).abs().max()
 
 
+def test_hip_graph_replay_matches_eager():
+    """RNRPipeline.render captured into a HIP graph (torch.cuda.graph) and replayed — with unrelated copies / reductions
+    in between, which is what broke hipMemsetAsync nodes — reproduces the eager frames bit for bit, also for new poses
+    written into the static input tensors."""
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    S = 128
+    sc = testing.tiny_scene(img_size=S, nf0=8, tex_size=64, tex_ch=24, nlat=31, nlon=62, seed=3)
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], sc['lp'], nf0=8,
+                       max_views=2, device=DEV)
+    va = {k: T(v).to(DEV) for k, v in scene.spiral_views(S, [10, 200]).items()}
+    vb = {k: T(v).to(DEV) for k, v in scene.spiral_views(S, [400, 650]).items()}
+    static = {k: v.clone() for k, v in va.items()}
+    args = lambda d: (d['proj'], d['pose'], d['proj_inv'], d['R_inv'])
+    eager_a = pipe.render(*args(va)).clone()
+    eager_b = pipe.render(*args(vb)).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.render(*args(static))
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = pipe.render(*args(static))
+    graph.replay()
+    assert torch.equal(out, eager_a)
+    assert float(torch.zeros(1 << 20, device=DEV).sum().item()) == 0.0      # an unrelated reduction + D2H copy
+    for k in static:
+        static[k].copy_(vb[k])
+    graph.replay()
+    assert torch.equal(out, eager_b)
+    for k in static:
+        static[k].copy_(va[k])
+    for _ in range(3):
+        graph.replay()
+    assert torch.equal(out, eager_a)
+
+
 def test_all_background_view():
     """Camera looking away from the mesh: every pixel is background (face index -1 wraps to the last face with zero
     weights, uv = (0,0), rays_uv = -1, network.py:176-190, 469-470).  The frame must still match the oracle."""
