@@ -11,7 +11,10 @@
  *     reference's <<<blocks, threads>>> launches use, rasterize_cuda_kernel.cu:615,629,670);
  *   - return value: 0 = success; non-zero = error, message available from rnr_last_error().
  *     Unlike the reference (which only printf()s kernel-launch failures, rasterize_cuda_kernel.cu:623-625)
- *     every launch is checked with hipGetLastError() and reported.
+ *     every launch is checked with hipGetLastError() and reported;
+ *   - the device entry points only enqueue kernels on `stream` (no allocation, no host synchronisation, no
+ *     hipMemset / hipMemcpy), so a sequence of calls can be captured into a HIP graph and replayed; no kernel uses
+ *     scratch memory.
  *
  * Each entry point cites the reference interface it replaces (paths relative to /root/reference).
  */

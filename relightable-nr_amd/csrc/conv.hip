@@ -1560,7 +1560,9 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
     if (int e = check_launch("pack_weight_kernel")) return e;
     if (d->flags & RNR_CONV_F32_EMU_ANY) {
         char* image = reinterpret_cast<char*>(packed + total);
-        RNR_HIP(hipMemsetAsync(image, 0, EMU_HEADER_BYTES, as_stream(stream)));
+        static_assert(EMU_HEADER_BYTES % sizeof(double) == 0, "header cleared as doubles");
+        hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(256), 0, as_stream(stream), reinterpret_cast<double*>(image),
+                           (long)(EMU_HEADER_BYTES / sizeof(double)));
         const dim3 grid((unsigned)((total + 255) / 256));
         if (d->flags & RNR_CONV_F32_EMU_F16X3) {
             const long nw = (long)(d->c_in0 + d->c_in1) * d->c_out * (d->kind == RNR_CONV3x3_REFLECT ? 9 : 16);
