@@ -435,7 +435,6 @@ conv_halo_kernel(const ConvParams P) {
     constexpr int ASLOTS = HP * 4;                         // float4 slots of one halo chunk (pixel x channel quad)
     constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
     constexpr int APS = (APT + TAPS - 1) / TAPS;           // halo float4 fetched per pipeline step
-    constexpr int ABUFS = 2;                               // the halo is double-buffered in LDS
     // two taps of MFMAs between a halo slice's fetch and its store cover the HBM latency (+0.4 %); the transposed conv at
     // three waves per SIMD has no registers for the second slice (it would spill to scratch)
     constexpr int HDIST = KIND == 2 ? 1 : RNR_HALO_HDIST;
@@ -449,7 +448,7 @@ conv_halo_kernel(const ConvParams P) {
     static_assert(BK == 16, "plane mapping assumes 16-channel chunks");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [ABUFS][ACH]
+    float* As = smem;                       // [2][ACH]: the halo is double-buffered in LDS
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
