@@ -358,15 +358,17 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
     const float a = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;      // 1 ulp reciprocal: the result only picks env-map taps
     const float s = a * a;
+    // explicit FMAs: this file is compiled with -ffp-contract=off (bit-exact tap indices elsewhere), which would turn
+    // every Horner step into a multiply and an add — the kernel is VALU-bound
     float p = 0.002899040700867772f;
-    p = p * s - 0.01637016236782074f;
-    p = p * s + 0.04338274151086807f;
-    p = p * s - 0.07582952827215195f;
-    p = p * s + 0.10688958317041397f;
-    p = p * s - 0.14219146966934204f;
-    p = p * s + 0.19995006918907166f;
-    p = p * s - 0.3333321213722229f;
-    p = p * s + 1.0f;
+    p = __builtin_fmaf(p, s, -0.01637016236782074f);
+    p = __builtin_fmaf(p, s, 0.04338274151086807f);
+    p = __builtin_fmaf(p, s, -0.07582952827215195f);
+    p = __builtin_fmaf(p, s, 0.10688958317041397f);
+    p = __builtin_fmaf(p, s, -0.14219146966934204f);
+    p = __builtin_fmaf(p, s, 0.19995006918907166f);
+    p = __builtin_fmaf(p, s, -0.3333321213722229f);
+    p = __builtin_fmaf(p, s, 1.0f);
     float r = p * a;
     if (ay > ax) r = 1.57079632679489662f - r;
     if (x < 0.0f) r = 3.14159265358979324f - r;
@@ -375,22 +377,22 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {
 __device__ __forceinline__ float fast_acosf(float x) {
     const float ax = fminf(fabsf(x), 1.0f);
     float p = -0.001102376147173345f;
-    p = p * ax + 0.006096228025853634f;
-    p = p * ax - 0.01627347804605961f;
-    p = p * ax + 0.03031114861369133f;
-    p = p * ax - 0.049957286566495895f;
-    p = p * ax + 0.08893882483243942f;
-    p = p * ax - 0.2145957499742508f;
-    p = p * ax + 1.570796251296997f;
+    p = __builtin_fmaf(p, ax, 0.006096228025853634f);
+    p = __builtin_fmaf(p, ax, -0.01627347804605961f);
+    p = __builtin_fmaf(p, ax, 0.03031114861369133f);
+    p = __builtin_fmaf(p, ax, -0.049957286566495895f);
+    p = __builtin_fmaf(p, ax, 0.08893882483243942f);
+    p = __builtin_fmaf(p, ax, -0.2145957499742508f);
+    p = __builtin_fmaf(p, ax, 1.570796251296997f);
     const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * p;
     return x < 0.0f ? 3.14159265358979324f - r : r;
 }
 
-// tanh(x) = 1 - 2 / (e^{2x} + 1) on v_exp_f32 / v_rcp_f32: absolute error ~1e-7 (what matters for tanh + 1, the light
-// transport factor), exact limits at +-inf; ocml's tanhf costs ~25 instructions and this kernel is VALU-bound.
-__device__ __forceinline__ float fast_tanhf(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^{2x}
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+// tanh(x) + 1 = 2 - 2 / (e^{2x} + 1) on v_exp_f32 / v_rcp_f32 (the light transport factor of the ray renderer): absolute
+// error ~1e-7, exact limits at +-inf; ocml's tanhf costs ~25 instructions and this kernel is VALU-bound.
+__device__ __forceinline__ float fast_tanh_plus1f(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 2.0f);
 }
 
 struct RayParams {
@@ -442,6 +444,8 @@ ray_render_kernel(const RayParams P) {
     const bool ray_live = is_diff ? rr < P.n_diff : rr < P.n_spec;
     const int r = is_diff ? P.n_spec + rr : rr;
     const long pix0 = wg_pix0 + lp0;
+    const long wg_n0 = wg_pix0 / P.hw;                       // workgroup-uniform (SALU)
+    const int wg_rem0 = (int)(wg_pix0 - wg_n0 * P.hw);
     const float* wg_net_in = P.net_in + wg_pix0 * P.c_pad;
     const float* wg_raw = P.unet_raw + wg_pix0 * P.c_out_pad;
     const float* wg_alpha = P.alpha + wg_pix0;
@@ -460,8 +464,8 @@ ray_render_kernel(const RayParams P) {
         for (int i = threadIdx.x; i < wg_valid * q_raw; i += 256) reinterpret_cast<float4*>(s_raw)[i] = g_raw[i];
         const float inv_q = 1.0f / (float)q_ni;
         for (int i = threadIdx.x; i < wg_valid * q_ni; i += 256) {
-            const int p = (int)(((float)i + 0.5f) * inv_q), q4 = i - p * q_ni;
-            reinterpret_cast<float4*>(s_ni)[i] = *reinterpret_cast<const float4*>(wg_net_in + (unsigned)(p * P.c_pad + 4 * q4));
+            const int p = (int)(((float)i + 0.5f) * inv_q), q4 = i - __mul24(p, q_ni);
+            reinterpret_cast<float4*>(s_ni)[i] = *reinterpret_cast<const float4*>(wg_net_in + (unsigned)(__mul24(p, P.c_pad) + 4 * q4));
         }
     }
     float al[RR_PIX];
@@ -475,8 +479,8 @@ ray_render_kernel(const RayParams P) {
         live[k] = ray_live && (lp0 + k < wg_valid);
         dx[k] = dy[k] = dz[k] = y0[k] = y1[k] = y2[k] = 0.f;
         if (live[k]) {      // lanes of a half-wave read 3-float records at a stride of 3 floats: conflict-free
-            const float* d = s_ni + (lp0 + k) * ni_need + 3 * r;
-            const float* yr = s_raw + (lp0 + k) * P.c_out_pad + 3 * r;
+            const float* d = s_ni + __mul24(lp0 + k, ni_need) + 3 * r;
+            const float* yr = s_raw + __mul24(lp0 + k, P.c_out_pad) + 3 * r;
             dx[k] = d[0]; dy[k] = d[1]; dz[k] = d[2];
             y0[k] = yr[0]; y1[k] = yr[1]; y2[k] = yr[2];
         }
@@ -487,7 +491,7 @@ ray_render_kernel(const RayParams P) {
 #pragma unroll
     for (int k = 0; k < RR_PIX; k++) {
         // rays_uv (render.py:96-102; network.py:469-470)
-        float u = fast_atan2f(dz[k], dx[k]) * (0.5f / RNR_PI_F) + 0.5f;
+        float u = __builtin_fmaf(fast_atan2f(dz[k], dx[k]), 0.5f / RNR_PI_F, 0.5f);
         float v = fast_acosf(dy[k]) * (1.0f / RNR_PI_F);
         const float bg = (al[k] == 0.0f) ? 1.0f : 0.0f;
         u = u * al[k] - bg;
@@ -499,6 +503,7 @@ ray_render_kernel(const RayParams P) {
     }
     // mean over the rays of a group as a multiplication by the reciprocal (one division per thread instead of six
     // correctly rounded ones per pixel; <= 1 ulp from network.py:505-513's `.sum(1) / num_ray`)
+    const int lp_w3 = P.lp_w * 3;
     const float inv_spec = 1.0f / (float)P.n_spec;
     const float inv_diff = P.n_diff > 0 ? 1.0f / (float)P.n_diff : 0.0f;
     float c0[RR_PIX], c1[RR_PIX], c2[RR_PIX];
@@ -510,18 +515,23 @@ ray_render_kernel(const RayParams P) {
 #ifdef RNR_ABLATE_RAY_FIXEDTAP
             const float* l00 = P.lp + (unsigned)(sub * 3); const float* l10 = l00 + 3; const float* l01 = l00 + 6; const float* l11 = l00 + 9;
 #else
-            const float* l00 = P.lp + (unsigned)((t.y0 * P.lp_w + t.x0) * 3);
-            const float* l10 = P.lp + (unsigned)((t.y1 * P.lp_w + t.x0) * 3);
-            const float* l01 = P.lp + (unsigned)((t.y0 * P.lp_w + t.x1) * 3);
-            const float* l11 = P.lp + (unsigned)((t.y1 * P.lp_w + t.x1) * 3);
+            // texel offsets with 24-bit multiplies (full rate; v_mul_lo_u32 runs at a quarter of it): the probe has far
+            // fewer than 2^24 floats
+            const unsigned r0 = __umul24((unsigned)t.y0, (unsigned)lp_w3), r1 = __umul24((unsigned)t.y1, (unsigned)lp_w3);
+            const unsigned q0 = __umul24((unsigned)t.x0, 3u), q1 = __umul24((unsigned)t.x1, 3u);
+            const float* l00 = P.lp + (r0 + q0);
+            const float* l10 = P.lp + (r1 + q0);
+            const float* l01 = P.lp + (r0 + q1);
+            const float* l11 = P.lp + (r1 + q1);
 #endif
-            const float col0 = l00[0] * t.w00 + l10[0] * t.w10 + l01[0] * t.w01 + l11[0] * t.w11;
-            const float col1 = l00[1] * t.w00 + l10[1] * t.w10 + l01[1] * t.w01 + l11[1] * t.w11;
-            const float col2 = l00[2] * t.w00 + l10[2] * t.w10 + l01[2] * t.w01 + l11[2] * t.w11;
-            // network.py:253 tanh; test_rnr.py:359 (y*0.5+0.5)*2 == y + 1 bit for bit (the two scalings by 2 are exact)
-            c0[k] = (fast_tanhf(y0[k] + b0) + 1.0f) * col0;
-            c1[k] = (fast_tanhf(y1[k] + b1) + 1.0f) * col1;
-            c2[k] = (fast_tanhf(y2[k] + b2) + 1.0f) * col2;
+            // (explicit FMAs, see fast_atan2f; the reference's torch ops round every product, <= 1 ulp apart)
+            const float col0 = __builtin_fmaf(l11[0], t.w11, __builtin_fmaf(l01[0], t.w01, __builtin_fmaf(l10[0], t.w10, l00[0] * t.w00)));
+            const float col1 = __builtin_fmaf(l11[1], t.w11, __builtin_fmaf(l01[1], t.w01, __builtin_fmaf(l10[1], t.w10, l00[1] * t.w00)));
+            const float col2 = __builtin_fmaf(l11[2], t.w11, __builtin_fmaf(l01[2], t.w01, __builtin_fmaf(l10[2], t.w10, l00[2] * t.w00)));
+            // network.py:253 tanh; test_rnr.py:359 (y*0.5+0.5)*2 = y + 1 (the two scalings by 2 are exact)
+            c0[k] = fast_tanh_plus1f(y0[k] + b0) * col0;
+            c1[k] = fast_tanh_plus1f(y1[k] + b1) * col1;
+            c2[k] = fast_tanh_plus1f(y2[k] + b2) * col2;
             // background pixels contribute exactly 0 whatever the network produced there (col = 0 by the uv = -1
             // mask); select rather than multiply: the out layer may have skipped the tile (rnr_conv2d_masked) and
             // left non-finite garbage.  Done here, after every load has landed, so the loads stay independent.
@@ -535,8 +545,11 @@ ray_render_kernel(const RayParams P) {
         const float d0 = __shfl_down(s0, 16, 64), d1 = __shfl_down(s1, 16, 64), d2 = __shfl_down(s2, 16, 64);
         const long pix = pix0 + k;
         if (sub == 0 && pix < P.npix) {
-            const float* ni = s_ni + (lp0 + k) * ni_need + 3 * (P.n_spec + P.n_diff) + 6;
-            const long n = pix / P.hw, rem = pix % P.hw;
+            const float* ni = s_ni + __mul24(lp0 + k, ni_need) + 3 * (P.n_spec + P.n_diff) + 6;
+            // view / in-view pixel from the workgroup's (scalar) quotient: no per-lane 64-bit division
+            int rem = wg_rem0 + lp0 + k;
+            long n = wg_n0;
+            while (rem >= P.hw) { rem -= P.hw; n += 1; }      // at most once unless a view has fewer pixels than a workgroup
             const float o[3] = {s0, s1, s2}, dd[3] = {d0, d1, d2};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
