@@ -603,13 +603,13 @@ conv_halo_kernel(const ConvParams P) {
         const int abuf = (c - s_begin) & 1;
         const bool next_chunk = c + 1 < s_end;
         ChunkSrc csn = chunk_src(next_chunk ? c + 1 : c);
-        float4 avr[2][APS];                 // halo slices in flight: fetched during tap t, stored after tap t + HDIST - 1
+        float4 avr[HDIST < 2 ? 2 : HDIST][APS];     // halo slices in flight: fetched during tap t, stored after tap t + HDIST - 1
 #pragma unroll
         for (int t = 0; t < TAPS; t++) {
             // the next tap's (or the next chunk's first) weights are requested before this tap's MFMAs
             if (t < TAPS - 1) load_b(breg[(t + 1) & 1], c, t + 1);
             else if (next_chunk) load_b(breg[TAPS & 1], c + 1, 0);
-            float4 (&av)[APS] = avr[t & 1];
+            float4 (&av)[APS] = avr[t % (HDIST < 2 ? 2 : HDIST)];
 #pragma unroll
             for (int u = 0; u < APS; u++) {
                 const int j = t * APS + u;
@@ -658,17 +658,22 @@ conv_halo_kernel(const ConvParams P) {
 #pragma unroll
                 for (int u = 0; u < APS; u++) {
                     const int j = ts * APS + u;
-                    if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, avr[ts & 1][u], j, abuf ^ 1);
+                    if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS)
+                        store_a(csn, avr[ts % (HDIST < 2 ? 2 : HDIST)][u], j, abuf ^ 1);
                 }
             }
 #endif
         }
 #if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
-        if (HDIST == 2 && (TAPS - 1) * APS < APT) {        // the slice of the last tap
+        // slices fetched during the last HDIST - 1 taps
+#pragma unroll
+        for (int ts = TAPS - (HDIST - 1); ts < TAPS; ts++) {
+            if (ts < 0 || ts * APS >= APT) continue;
 #pragma unroll
             for (int u = 0; u < APS; u++) {
-                const int j = (TAPS - 1) * APS + u;
-                if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, avr[(TAPS - 1) & 1][u], j, abuf ^ 1);
+                const int j = ts * APS + u;
+                if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS)
+                    store_a(csn, avr[ts % (HDIST < 2 ? 2 : HDIST)][u], j, abuf ^ 1);
             }
         }
 #endif
