@@ -338,6 +338,11 @@ def main():
                          for k in acc}
             res['stages']['raster']['note'] = ('not an HBM-bound stage: 65 k faces are binned and edge-tested per view '
                                                '(VALU / latency bound); the HBM figure is given for completeness')
+            res['stages']['shade_inputs']['note'] = ('arithmetic-bound (PMC: vector ALUs issue 74 % of the kernel cycles, '
+                                                     'profiles/README.md); the HBM figure is the SURVEY 8(d) yardstick')
+            res['stages']['ray_render']['note'] = ('arithmetic-bound (PMC: vector ALUs saturated: 26 rays per pixel with '
+                                                   'atan2 / acos / tanh each, profiles/README.md); the HBM figure is the '
+                                                   'SURVEY 8(d) yardstick')
         def timed(p):
             def st(s):
                 lo = (s % (args.steps + args.warmup)) * V
