@@ -296,6 +296,37 @@ int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
                       const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h, int in_w,
                       void* workspace, size_t workspace_bytes, const uint8_t* tile_mask, void* stream);
 
+/*
+ * The convolution of the product path (rnr_amd.unet.UNetPlan): rnr_conv2d_masked plus what the reference runs as separate
+ * passes behind it — the train-mode BatchNorm2d that follows the convolution (pytorch_prototyping.py:117-120, 250-268,
+ * 154-161; per-view batch statistics, test_rnr.py:229-233) — inside ONE launch:
+ *   bn != NULL && bn->gamma != NULL: the workgroups add the per-view, per-channel sum / sum of squares of out_raw into
+ *     statistics shards inside `sync`; the last workgroup of a view to arrive turns them into
+ *       scale[n,c] = gamma[c] / sqrt(var_biased + eps),  shift[n,c] = beta[c] - mean * scale[n,c]   (rnr_bn_finalize)
+ *     and leaves the shards at zero.  Channels >= c_out of scale / shift get 0.
+ *   split-K (small maps): the slices of a tile meet inside the launch (the last one to arrive adds the accumulator
+ *     images in slice order) when there are at most 4 of them; deeper splits keep the reduce kernel, which then also
+ *     finalises the BatchNorm.
+ * `sync` (rnr_conv_sync_bytes(d, max_views, in_h, in_w) bytes, 256-byte aligned): arrival counters and statistics.  The
+ * caller zero-fills it ONCE; every call expects zeros and leaves zeros, also for a different num_views <= max_views.  One
+ * buffer per convolution in flight (calls on the same stream may share one).  After a failed launch: zero it again.
+ * Run-to-run reproducibility: the statistics are floating-point atomics (order varies), so scale / shift — and
+ * everything downstream — may differ in the last bits between runs, exactly like rnr_conv2d + rnr_bn_finalize; the
+ * in-launch split-K combine itself is order-independent.
+ */
+typedef struct rnr_conv_bn {
+    const float* gamma; /* [c_out] BatchNorm weight; NULL = no BatchNorm behind this convolution */
+    const float* beta;  /* [c_out] */
+    float* scale;       /* [N, c_out_pad] out */
+    float* shift;       /* [N, c_out_pad] out */
+    float eps;
+} rnr_conv_bn;
+size_t rnr_conv_sync_bytes(const rnr_conv_desc* d, int max_views, int in_h, int in_w);
+int rnr_conv2d_fused(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                     const float* weight_packed, float* out_raw, const rnr_conv_bn* bn, int num_views, int in_h, int in_w,
+                     void* workspace, size_t workspace_bytes, void* sync, size_t sync_bytes, const uint8_t* tile_mask,
+                     void* stream);
+
 /* stats [N,c_pad,2] (sum, sumsq over `count` pixels) + gamma/beta [channels] -> scale/shift [N,c_pad]:
  * scale = gamma / sqrt(var_biased + eps), shift = beta - mean * scale  (BatchNorm2d in train mode: per-view
  * batch statistics, biased variance); channels >= `channels` get scale = shift = 0. */

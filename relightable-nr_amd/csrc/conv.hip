@@ -32,8 +32,17 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 16;
 constexpr int CTHREADS = 256;
 #ifndef RNR_SPLITK_BELOW
-#define RNR_SPLITK_BELOW 256
-#define RNR_SPLITK_TARGET 512
+#define RNR_SPLITK_BELOW 257        // one workgroup per CU (a single wave per SIMD) is split two ways: 146 vs 156 ... 266 vs 304 us on the
+#define RNR_SPLITK_TARGET 512       // 256-tile layers at one view per call
+#endif
+#ifndef RNR_COMBINE_MAX_BYTES
+#define RNR_COMBINE_MAX_BYTES (256 * 1024)      // four 128 x 128 images, sixteen 64 x 64 ones
+#endif
+#ifndef RNR_SMALL_TILE_BELOW
+#define RNR_SMALL_TILE_BELOW 128     // fewer 128 x 128 tiles than this: 64 x 64 tiles (make_plan)
+#endif
+#ifndef RNR_FUSED_BN_MIN_WGS
+#define RNR_FUSED_BN_MIN_WGS 256     // in-kernel BatchNorm finalise for grids larger than this
 #endif
 #ifndef RNR_NATIVE_BIG_MIN
 #define RNR_NATIVE_BIG_MIN 512     // measured: 512 >= 1024, 2048 at 8, 4, 2 views per launch, all equal at 1
@@ -66,7 +75,18 @@ struct ConvParams {
     long slab_stride;   // floats between split-K slabs
     int mtiles, ntiles, zdim;   // logical grid; the launch is 1-D and remapped per XCD (see tile_coords)
     const uint8_t* tile_mask;   // optional [mtiles]: 0 = nobody reads this pixel tile's output, skip it (halo kernels)
+    // ---- rnr_conv2d_fused: producer-side BatchNorm and in-launch split-K combine (all zero on the legacy entry points) ----
+    long stats_shard;           // doubles between the statistics shards (a workgroup adds into shard blockIdx % n_shards)
+    int n_shards;               // 1 (legacy) or STAT_SHARDS
+    unsigned* arrive;           // arrival counters of the statistics: [N] (arrive_per_view) or [1]; NULL = no in-kernel finalise
+    int arrive_per_view;
+    unsigned n_arrive;          // arrivals that complete a counter
+    const float* gamma; const float* beta; float* scale; float* shift;
+    float eps; double count;    // pixels per view behind one statistic
+    unsigned* tile_arrive;      // [par * mtiles * ntiles] split-K slices of a tile that have published their slab; NULL = legacy slabs + reduce kernel
+    float* slabs;               // in-launch combine: [splitk][tile][wave][i][j][4 quads][64 lanes][4] accumulator images
 };
+constexpr int STAT_SHARDS = 8;  // one per XCD: at one view per call every workgroup of a layer hits the same 2 * c_out words
 
 // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only), and each XCD has a
 // private 4 MiB L2.  Give every XCD a contiguous run of logical tiles so that vertically adjacent pixel tiles (which
@@ -95,6 +115,160 @@ __device__ __forceinline__ float act_slope(int act) {
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
     return fmaxf(v, act_slope(act) * v);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Producer-side BatchNorm and in-launch split-K combine (rnr_conv2d_fused).
+//
+// One view per call (the reference's mode, test_rnr.py:265) makes a convolution a 40 - 350 us kernel; the 17
+// bn_finalize launches and 9 split-K reduce launches behind them cost 6 % of the U-Net there.  Both are folded
+// into the convolution's epilogue with arrival counters:
+//   * batch statistics are added into one of STAT_SHARDS copies (workgroup b -> shard b % 8, i.e. its XCD), the
+//     workgroup waits for the acknowledgement of its atomics, and draws a ticket; the workgroup that draws the
+//     last ticket of a view sums the shards, writes scale / shift and leaves statistics and counter at zero.
+//     Statistics and counters are touched by agent-scope atomics only (add / load / store meet at the memory
+//     side, MI355X_MICROARCH.md "8-B agent atomics both sides"), so no fence is involved; scale / shift are plain
+//     stores read by the next kernel of the stream;
+//   * a split-K slice stores its accumulators as a write-through (sc1) register image — 16 B per lane, the order
+//     the registers have —, drains, and draws a ticket of its tile; the last slice adds all images IN SLICE ORDER
+//     (its own included: the sum does not depend on who arrives last) with sc1 loads and runs the normal epilogue.
+// Counters and statistics are zero before and after every call; the host zeroes them once.
+// ------------------------------------------------------------------------------------------------
+#define RNR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+typedef unsigned int uintx4_t __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+constexpr int AUX_SC1 = 16;         // write-through / L1-bypassing buffer access
+
+__device__ __forceinline__ double* stat_slot(const ConvParams& P, int n, int col) {
+    return P.stats + (size_t)(blockIdx.x & (unsigned)(P.n_shards - 1)) * P.stats_shard + ((size_t)n * P.c_out_pad + col) * 2;
+}
+
+// scale / shift of views [n_first, n_first + n_views) from the summed shards (the arithmetic of bn_finalize_kernel).
+// The (sum, sum of squares) pair of a channel is one 16-byte sc1 load per shard — L1-bypassing like the 8-byte agent-scope
+// atomic load, but all STAT_SHARDS of them are in flight at once (a chain of __hip_atomic_load is issued one at a time:
+// 16 round trips, 20 us at the end of a 150 us kernel) — and one 16-byte sc1 store of zeros.
+__device__ __forceinline__ void bn_finalize_views(const ConvParams& P, int n_first, int n_views, int tid) {
+    const int total = n_views * P.c_out_pad;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.stats, 0, 0x7fffffff, 0x27000);
+    const uintx4_t zero4 = {0u, 0u, 0u, 0u};
+    typedef double doublex2 __attribute__((ext_vector_type(2)));
+    for (int i = tid; i < total; i += CTHREADS) {
+        const int idx = n_first * P.c_out_pad + i;
+        const int c = i % P.c_out_pad;
+        doublex2 part[STAT_SHARDS];
+#pragma unroll
+        for (int sh = 0; sh < STAT_SHARDS; sh++) {
+            part[sh] = doublex2{0.0, 0.0};
+            if (sh < P.n_shards)
+                part[sh] = __builtin_bit_cast(doublex2, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            rsrc, idx * 16, (int)(sh * P.stats_shard * 8), AUX_SC1));
+        }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int sh = 0; sh < STAT_SHARDS; sh++) {
+            s1 += part[sh][0];
+            s2 += part[sh][1];
+            if (sh < P.n_shards)
+                __builtin_amdgcn_raw_buffer_store_b128(zero4, rsrc, idx * 16, (int)(sh * P.stats_shard * 8), AUX_SC1);
+        }
+        float sc = 0.f, sf = 0.f;
+        if (c < P.c_out) {
+            const double mean = s1 / P.count;
+            double var = s2 / P.count - mean * mean;    // biased variance
+            var = var < 0.0 ? 0.0 : var;
+            const double g = (double)P.gamma[c] / sqrt(var + (double)P.eps);
+            sc = (float)g;
+            sf = (float)((double)P.beta[c] - mean * g);
+        }
+        P.scale[idx] = sc;
+        P.shift[idx] = sf;
+    }
+}
+
+// Every thread has issued what it publishes (statistics atomics, slab stores).  Returns the ticket in thread 0.
+__device__ __forceinline__ unsigned publish_and_draw(unsigned* counter, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // acknowledged by the memory side
+    __syncthreads();
+    unsigned t = 0;
+    if (tid == 0) t = __hip_atomic_fetch_add(counter, 1u, RNR_RLX_AGENT);
+    return t;
+}
+// thread 0 holds the ticket; true in every thread of the workgroup that drew the last one (which resets the counter)
+__device__ __forceinline__ bool drew_last(unsigned* counter, unsigned ticket, unsigned expected, int tid, int* flag) {
+    if (tid == 0) {
+        const int last = ticket == expected - 1u ? 1 : 0;
+        *flag = last;
+        if (last) __hip_atomic_store(counter, 0u, RNR_RLX_AGENT);
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// statistics published -> ticket -> (caller's stores overlap the round trip) -> finalise.  n: the view of this workgroup
+// (halo kernels) or -1 (one counter for the whole launch).
+struct BnArrival { unsigned* counter; unsigned ticket; };
+__device__ __forceinline__ BnArrival bn_arrive(const ConvParams& P, int n, int tid) {
+    BnArrival a;
+    a.counter = P.arrive + (P.arrive_per_view && n >= 0 ? n : 0);
+    a.ticket = publish_and_draw(a.counter, tid);
+    return a;
+}
+__device__ __forceinline__ void bn_complete(const ConvParams& P, const BnArrival& a, int n, int tid, int* flag) {
+    if (drew_last(a.counter, a.ticket, P.n_arrive, tid, flag)) {
+        if (P.arrive_per_view && n >= 0) bn_finalize_views(P, n, 1, tid);
+        else bn_finalize_views(P, 0, P.N, tid);
+    }
+}
+
+// accumulator images of a wave: [i][j][quad q][lane][4 floats]
+template <int WM, int WN>
+__device__ __forceinline__ void slab_store(float* base, const floatx16 (&acc)[WM][WN], int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x27000);
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsrc, lane * 16,
+                                                       ((i * WN + j) * 4 + q) * 1024, AUX_SC1);
+            }
+}
+template <int WM, int WN>
+__device__ __forceinline__ void slab_add(const float* base, floatx16 (&acc)[WM][WN], int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x27000);
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  rsrc, lane * 16, ((i * WN + j) * 4 + q) * 1024, AUX_SC1));
+                acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1]; acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+            }
+}
+// The split-K slices of a tile meet here.  Returns false in the slices that are done (their slab is published), true
+// in the last one, whose accumulators then hold the sum over all slices.
+template <int WM, int WN>
+__device__ __forceinline__ bool splitk_combine(const ConvParams& P, floatx16 (&acc)[WM][WN], int tile, int split, int wave,
+                                               int lane, int tid, int* flag) {
+    constexpr size_t WAVE_FLOATS = (size_t)WM * WN * 1024, TILE_FLOATS = 4 * WAVE_FLOATS;
+    const size_t ntiles_all = (size_t)P.mtiles * P.ntiles * (P.zdim / P.splitk);
+    float* mine = P.slabs + ((size_t)split * ntiles_all + tile) * TILE_FLOATS + wave * WAVE_FLOATS;
+    slab_store<WM, WN>(mine, acc, lane);
+    const unsigned t = publish_and_draw(P.tile_arrive + tile, tid);
+    if (!drew_last(P.tile_arrive + tile, t, (unsigned)P.splitk, tid, flag)) return false;
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+    for (int s = 0; s < P.splitk; s++)
+        slab_add<WM, WN>(P.slabs + ((size_t)s * ntiles_all + tile) * TILE_FLOATS + wave * WAVE_FLOATS, acc, lane);
+    return true;
 }
 
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN>
@@ -326,7 +500,7 @@ conv_mfma_kernel(const ConvParams P) {
                         s1 += (double)red[(w * BN + tid) * 2 + 0];
                         s2 += (double)red[(w * BN + tid) * 2 + 1];
                     }
-                    double* st = P.stats + ((size_t)n_tile * P.c_out_pad + col) * 2;
+                    double* st = stat_slot(P, n_tile, col);
                     atomicAdd(st + 0, s1);
                     atomicAdd(st + 1, s2);
                 }
@@ -344,13 +518,17 @@ conv_mfma_kernel(const ConvParams P) {
                             const int col = n0 + wn0 + 32 * j + l31;
                             if (col < P.c_out) {
                                 const float v = acc[i][j][g];
-                                double* st = P.stats + ((size_t)n * P.c_out_pad + col) * 2;
+                                double* st = stat_slot(P, n, col);
                                 atomicAdd(st + 0, (double)v);
                                 atomicAdd(st + 1, (double)v * (double)v);
                             }
                         }
                     }
                 }
+        }
+        if (P.arrive) {      // producer-side BatchNorm: one counter for the launch (tiles may straddle views here)
+            const BnArrival a = bn_arrive(P, -1, tid);
+            bn_complete(P, a, -1, tid, reinterpret_cast<int*>(&Bs[0][0]));
         }
     }
 }
@@ -682,8 +860,13 @@ conv_halo_kernel(const ConvParams P) {
     }
 
     // ---- epilogue ----
+    int* flag = reinterpret_cast<int*>(As + WAVES_M * BN * 2);      // behind the statistics scratch; LDS is free after the last barrier
+    // in-launch split-K combine (128 x 128 tiles and smaller: the plans that split K): only the last slice of a tile goes
+    // on, holding the sum
+    if (!R16 && WM * WN <= 4 && P.tile_arrive) {
+        if (!splitk_combine<WM, WN>(P, acc, (par * P.mtiles + mt_) * P.ntiles + nt_, split, wave, lane, tid, flag)) return;
+    }
     float* out = P.out + (size_t)split * P.slab_stride;
-    store_acc_tiles<KIND, WM, WN, TW>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h);
     if (R16) {   // C layout of the 16x16 tiles: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int col = n0 + wn0 + WN * 32 + l15;
 #pragma unroll
@@ -699,7 +882,8 @@ conv_halo_kernel(const ConvParams P) {
             }
         }
     }
-    if (P.stats && P.splitk == 1) {
+    const bool with_stats = P.stats && (P.splitk == 1 || P.tile_arrive);
+    if (with_stats) {
         float* red = As;   // [WAVES_M][BN][2]; LDS is free after the last barrier
 #pragma unroll
         for (int j = 0; j < WN; j++) {
@@ -748,11 +932,18 @@ conv_halo_kernel(const ConvParams P) {
                     s1 += (double)red[(w * BN + tid) * 2 + 0];
                     s2 += (double)red[(w * BN + tid) * 2 + 1];
                 }
-                double* st = P.stats + ((size_t)n * P.c_out_pad + col) * 2;
+                double* st = stat_slot(P, n, col);
                 atomicAdd(st + 0, s1);
                 atomicAdd(st + 1, s2);
             }
         }
+    }
+    if (with_stats && P.arrive) {       // producer-side BatchNorm: the output stores overlap the ticket's round trip
+        const BnArrival a = bn_arrive(P, n, tid);
+        store_acc_tiles<KIND, WM, WN, TW>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h);
+        bn_complete(P, a, n, tid, flag);
+    } else {
+        store_acc_tiles<KIND, WM, WN, TW>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h);
     }
 }
 
@@ -1081,9 +1272,13 @@ conv_halo_emu_kernel(const ConvParams P) {
     // two commutes with every fp32 rounding involved, so this equals scaling the accumulators first; scaling all 128 of
     // them in place made the compiler keep both copies and spill)
     const float winv = FMT == 1 ? *reinterpret_cast<const float*>(P.weight_emu) : 1.0f;
+    int* flag = reinterpret_cast<int*>(As) + WAVES_M * BN * 2;      // behind the statistics scratch
+    if (WM * WN <= 4 && P.tile_arrive) {    // in-launch split-K combine (images hold the unscaled accumulators)
+        if (!splitk_combine<WM, WN>(P, acc, (par * P.mtiles + mt_) * P.ntiles + nt_, split, wave, lane, tid, flag)) return;
+    }
     float* out = P.out + (size_t)split * P.slab_stride;
-    store_acc_tiles<KIND, WM, WN, TW, FMT == 1>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h, winv);
-    if (P.stats && P.splitk == 1) {
+    const bool with_stats = P.stats && (P.splitk == 1 || P.tile_arrive);
+    if (with_stats) {
         float* red = reinterpret_cast<float*>(As);   // [WAVES_M][BN][2]; LDS is free after the last barrier
 #pragma unroll
         for (int j = 0; j < WN; j++) {
@@ -1115,11 +1310,18 @@ conv_halo_emu_kernel(const ConvParams P) {
                     s1 += (double)red[(w * BN + tid) * 2 + 0];
                     s2 += (double)red[(w * BN + tid) * 2 + 1];
                 }
-                double* st = P.stats + ((size_t)n * P.c_out_pad + col) * 2;
+                double* st = stat_slot(P, n, col);
                 atomicAdd(st + 0, s1);
                 atomicAdd(st + 1, s2);
             }
         }
+    }
+    if (with_stats && P.arrive) {       // producer-side BatchNorm
+        const BnArrival a = bn_arrive(P, n, tid);
+        store_acc_tiles<KIND, WM, WN, TW, FMT == 1>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h, winv);
+        bn_complete(P, a, n, tid, flag);
+    } else {
+        store_acc_tiles<KIND, WM, WN, TW, FMT == 1>(P, out, acc, n, y0, x0, py, px, wave_m, n0, wn0, l31, h, winv);
     }
 }
 
@@ -1188,9 +1390,12 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
 // per 256-thread workgroup), so even the 16x16 maps spread over >= 128 workgroups.
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk, float* __restrict__ out,
-                     double* __restrict__ stats, long rows, int rows_per_view, int c_out, int c_out_pad) {
+                     long rows, int rows_per_view, const ConvParams P) {
     __shared__ float red[16][64][2];
-    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    double* const stats = P.stats;
+    const int c_out = P.c_out, c_out_pad = P.c_out_pad;
+    const int tid = threadIdx.x;
+    const int cq = tid & 15, ry = tid >> 4;
     const int col = blockIdx.y * 64 + cq * 4;
     const long r0 = (long)blockIdx.x * 16;
     const long m = r0 + ry;
@@ -1212,30 +1417,42 @@ splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int spli
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (col + k < c_out) {
-                    double* st = stats + ((size_t)(m / rows_per_view) * c_out_pad + col + k) * 2;
+                    double* st = stat_slot(P, (int)(m / rows_per_view), col + k);
                     atomicAdd(st + 0, (double)vv[k]);
                     atomicAdd(st + 1, (double)vv[k] * (double)vv[k]);
                 }
         }
-        return;
-    }
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        red[ry][cq * 4 + k][0] = live ? vv[k] : 0.f;
-        red[ry][cq * 4 + k][1] = live ? vv[k] * vv[k] : 0.f;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = blockIdx.y * 64 + threadIdx.x;
-        if (c < c_out) {
-            double a = 0.0, b2 = 0.0;
+        for (int k = 0; k < 4; k++) {
+            red[ry][cq * 4 + k][0] = live ? vv[k] : 0.f;
+            red[ry][cq * 4 + k][1] = live ? vv[k] * vv[k] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = blockIdx.y * 64 + tid;
+            if (c < c_out) {
+                double a = 0.0, b2 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { a += (double)red[r][threadIdx.x][0]; b2 += (double)red[r][threadIdx.x][1]; }
-            double* st = stats + ((size_t)(r0 / rows_per_view) * c_out_pad + c) * 2;
-            atomicAdd(st + 0, a);
-            atomicAdd(st + 1, b2);
+                for (int r = 0; r < 16; r++) { a += (double)red[r][tid][0]; b2 += (double)red[r][tid][1]; }
+                double* st = stat_slot(P, (int)(r0 / rows_per_view), c);
+                atomicAdd(st + 0, a);
+                atomicAdd(st + 1, b2);
+            }
         }
     }
+    if (P.arrive) {      // producer-side BatchNorm: one counter for the launch
+        const BnArrival a = bn_arrive(P, -1, tid);
+        bn_complete(P, a, -1, tid, reinterpret_cast<int*>(&red[0][0][0]));
+    }
+}
+
+// rnr_conv2d_fused's BatchNorm as its own launch: convolutions whose workgroups all finish together (one workgroup per CU,
+// the split-K reduce kernel) gain nothing from drawing tickets — three dependent round trips at the end of the kernel cost
+// more than the 4.7 us of this launch (measured at one view per call: +8 ... +15 us on the 256-workgroup layers).
+__global__ void __launch_bounds__(CTHREADS)
+bn_finalize_shards_kernel(const ConvParams P) {
+    bn_finalize_views(P, blockIdx.x, 1, threadIdx.x);
 }
 
 template <bool RESET>
@@ -1468,6 +1685,17 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
         p->halo = 1;
     }
+    // exact-fp32 kernels, small maps (the 32^2 / 16^2 layers at one view per call): when 128 x 128 tiles would have to split
+    // K more than four ways to fill the chip, 64 x 64 tiles (32 x 2 or 16 x 4 pixels, one MFMA block per wave) give four
+    // times as many tiles: a shallow split whose slices meet inside the launch instead of 16 - 32 slabs and a reduce kernel
+    if (p->halo && !(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && p->bm == 128) {
+        const long t128 = (long)N * (p->Ho / th) * (p->Wo / p->tw) * p->ntiles * p->par;
+        const int th64 = p->tw == 32 ? 2 : 4;
+        if (t128 < RNR_SMALL_TILE_BELOW && p->Ho % th64 == 0) {
+            p->cfg = 3; p->bm = 64; p->bn = 64; th = th64;
+            p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+        }
+    }
     // the halo kernels address a view with 32-bit element offsets
     const long view_elems = (long)H * W * (d->c_in0_pad > d->c_in1_pad ? d->c_in0_pad : d->c_in1_pad);
     if (view_elems >= (1L << 30)) p->halo = 0;
@@ -1477,8 +1705,11 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     }
     const long tiles = (long)p->mtiles * p->ntiles * p->par;
     int sk = 1;
-    if (tiles < RNR_SPLITK_BELOW) {      // fewer workgroups than ~2-3 per CU: split K so the 256 CUs stay filled
-        sk = (int)((RNR_SPLITK_TARGET + tiles - 1) / tiles);
+    // (experiments: RNR_SPLITK_BELOW / RNR_SPLITK_TARGET in the environment override the compiled-in thresholds)
+    static const int sk_below = [] { const char* e = getenv("RNR_SPLITK_BELOW"); return e ? atoi(e) : RNR_SPLITK_BELOW; }();
+    static const int sk_target = [] { const char* e = getenv("RNR_SPLITK_TARGET"); return e ? atoi(e) : RNR_SPLITK_TARGET; }();
+    if (tiles < sk_below) {      // fewer workgroups than ~2-3 per CU: split K so the 256 CUs stay filled
+        sk = (int)((sk_target + tiles - 1) / tiles);
         // split granularity: K-chunks x taps for the gather kernel, K-chunks (all nine taps) for the halo kernel
         const int units = p->halo ? p->chunks_per_tap : p->kt_total / 4;
         const int max_sk = units > 0 ? units : 1;
@@ -1507,7 +1738,9 @@ static void launch_halo_emu(const ConvPlan& pl, const dim3 grid, const ConvParam
 template <int KIND>
 static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
     const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
-    if (pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 2, 2, 0, 16>(grid, P, st);       // 16 x 8 pixel tiles, 128 columns
+    if (pl.cfg == 3 && pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 1, 1, 0, 16>(grid, P, st);      // 16 x 4 pixel tiles, 64 columns
+    else if (pl.cfg == 3) launch_halo_cfg<KIND, 2, 2, 1, 1, 0>(grid, P, st);                    // 32 x 2 pixel tiles, 64 columns
+    else if (pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 2, 2, 0, 16>(grid, P, st);       // 16 x 8 pixel tiles, 128 columns
     else if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
     else if (pl.cfg == 1) launch_halo_cfg<KIND, 4, 1, 2, 2, 1>(grid, P, st);      // 256 x 80
     else if (pl.bm == 256) launch_halo_cfg<KIND, 2, 2, 4, 2, 0>(grid, P, st);
@@ -1581,12 +1814,47 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
     return 0;
 }
 
+// split-K slices of a tile meet inside the launch (splitk_combine) when there are few of them: the last slice reads
+// splitk accumulator images, a serial tail that a chip-wide reduce kernel beats for deep splits
+static bool combines_in_launch(const ConvPlan& pl) {
+    return pl.halo && pl.splitk > 1 && pl.cfg != 1 && pl.bm * pl.bn <= 128 * 128 &&
+           (long)pl.splitk * pl.bm * pl.bn * (long)sizeof(float) <= RNR_COMBINE_MAX_BYTES;
+}
+static size_t combine_slab_floats(const ConvPlan& pl) {     // one accumulator image per (slice, tile): bm x bn floats
+    return (size_t)pl.splitk * pl.par * pl.mtiles * pl.ntiles * pl.bm * pl.bn;
+}
+
 extern "C" size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
     if (!d || num_views <= 0) return 0;
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
     if (pl.splitk <= 1) return 256;
-    return (size_t)pl.splitk * num_views * pl.OH * pl.OW * d->c_out_pad * sizeof(float) + 256;
+    const size_t legacy = (size_t)pl.splitk * num_views * pl.OH * pl.OW * d->c_out_pad * sizeof(float) + 256;
+    const size_t fused = combines_in_launch(pl) ? combine_slab_floats(pl) * sizeof(float) + 256 : 0;
+    return legacy > fused ? legacy : fused;
+}
+
+// rnr_conv2d_fused's sync buffer for one call: [arrival counters | tile counters | statistics shards]
+struct SyncLayout { size_t arrive, tiles, stats, total; };
+static SyncLayout sync_layout(const rnr_conv_desc* d, const ConvPlan& pl, int num_views) {
+    SyncLayout L;
+    L.arrive = 0;
+    L.tiles = align_up(sizeof(unsigned) * (size_t)(num_views + 1), 256);
+    L.stats = L.tiles + align_up(sizeof(unsigned) * (size_t)pl.par * pl.mtiles * pl.ntiles, 256);
+    L.total = L.stats + sizeof(double) * 2 * (size_t)STAT_SHARDS * num_views * d->c_out_pad;
+    return L;
+}
+
+extern "C" size_t rnr_conv_sync_bytes(const rnr_conv_desc* d, int max_views, int in_h, int in_w) {
+    if (!d || max_views <= 0) return 0;
+    size_t need = 0;
+    for (int n = 1; n <= max_views; n++) {      // the plan (tile shape, split depth) depends on the number of views
+        ConvPlan pl;
+        make_plan(d, n, in_h, in_w, &pl);
+        const size_t t = sync_layout(d, pl, n).total;
+        need = t > need ? t : need;
+    }
+    return need;
 }
 
 extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
@@ -1609,17 +1877,9 @@ extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha,
     return check_launch("active_tile_kernel");
 }
 
-extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
-                          const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
-                          int in_w, void* workspace, size_t workspace_bytes, void* stream) {
-    return rnr_conv2d_masked(d, src0, src1, weight_packed, out_raw, stats, num_views, in_h, in_w, workspace,
-                             workspace_bytes, nullptr, stream);
-}
-
-extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
-                                 const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
-                                 int in_w, void* workspace, size_t workspace_bytes, const uint8_t* tile_mask,
-                                 void* stream) {
+static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1, const float* weight_packed,
+                      float* out_raw, double* stats, const rnr_conv_bn* bn, void* sync, size_t sync_bytes, int num_views,
+                      int in_h, int in_w, void* workspace, size_t workspace_bytes, const uint8_t* tile_mask, void* stream) {
     if (int e = check_desc(d, "rnr_conv2d")) return e;
     RNR_REQUIRE(src0 && src0->data && weight_packed && out_raw, "rnr_conv2d: null pointer argument");
     RNR_REQUIRE(src0->channels == d->c_in0_pad, "rnr_conv2d: src0 has %d channels, descriptor says %d",
@@ -1631,6 +1891,9 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
                 in_h, in_w);
     RNR_REQUIRE(d->kind != RNR_CONV4x4S2_REFLECT || (in_h % 2 == 0 && in_w % 2 == 0),
                 "rnr_conv2d: stride-2 conv needs even input size");
+    const bool fused = sync != nullptr;          // rnr_conv2d_fused
+    const bool with_bn = fused && bn && bn->gamma;
+    if (with_bn) RNR_REQUIRE(bn->beta && bn->scale && bn->shift, "rnr_conv2d_fused: null BatchNorm pointer");
     hipStream_t st = as_stream(stream);
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
@@ -1641,25 +1904,61 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
         P.src_data[1] = src1->data; P.src_scale[1] = src1->scale; P.src_shift[1] = src1->shift;
         P.src_c[1] = src1->channels; P.src_act[1] = src1->act;
     }
-    P.weight = weight_packed; P.stats = stats;
+    P.weight = weight_packed; P.stats = stats; P.n_shards = 1;
     P.N = num_views; P.H = in_h; P.W = in_w; P.Ho = pl.Ho; P.Wo = pl.Wo; P.OH = pl.OH; P.OW = pl.OW; P.M = pl.M;
     P.c_out = d->c_out; P.c_out_pad = d->c_out_pad; P.wstride = weight_row_stride(d->c_out_pad);
     P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
     P.splitk = pl.splitk;
     P.mtiles = pl.mtiles; P.ntiles = pl.ntiles; P.zdim = pl.splitk * pl.par;
     if (tile_mask) {
-        RNR_REQUIRE(!stats, "rnr_conv2d_masked: skipped tiles would falsify the batch statistics (stats must be NULL)");
+        RNR_REQUIRE(!stats && !with_bn, "rnr_conv2d_masked: skipped tiles would falsify the batch statistics (no statistics / BatchNorm with a mask)");
         RNR_REQUIRE(rnr_conv_tile_count(d, num_views, in_h, in_w) > 0,
                     "rnr_conv2d_masked: this convolution does not run on maskable pixel tiles");
         P.tile_mask = tile_mask;
     }
     const size_t out_floats = (size_t)num_views * pl.OH * pl.OW * d->c_out_pad;
+    const long grid_wgs = (long)pl.mtiles * pl.ntiles * pl.splitk * pl.par;
+    const bool combine = fused && combines_in_launch(pl);
+    bool in_kernel_bn = false;
+    if (fused) {
+        const SyncLayout L = sync_layout(d, pl, num_views);
+        RNR_REQUIRE(sync_bytes >= L.total, "rnr_conv2d_fused: sync buffer too small (%zu < %zu, see rnr_conv_sync_bytes)",
+                    sync_bytes, L.total);
+        char* sb = reinterpret_cast<char*>(sync);
+        if (combine) P.tile_arrive = reinterpret_cast<unsigned*>(sb + L.tiles);
+        if (with_bn) {
+            P.stats = reinterpret_cast<double*>(sb + L.stats);
+            P.n_shards = STAT_SHARDS;
+            P.stats_shard = 2L * num_views * d->c_out_pad;
+            P.gamma = bn->gamma; P.beta = bn->beta; P.scale = bn->scale; P.shift = bn->shift;
+            P.eps = bn->eps; P.count = (double)pl.OH * pl.OW;
+            // tickets only where workgroups finish at different times: more than one workgroup per CU (see
+            // bn_finalize_shards_kernel); the others get the finalise as a launch of its own
+            in_kernel_bn = (pl.splitk == 1 || combine) && grid_wgs > RNR_FUSED_BN_MIN_WGS;
+            if (in_kernel_bn) {
+                P.arrive = reinterpret_cast<unsigned*>(sb + L.arrive);
+                if (pl.halo) {      // the halo kernels' tiles lie inside one view
+                    P.arrive_per_view = 1;
+                    P.n_arrive = (unsigned)((long)pl.mtiles * pl.ntiles * pl.par / num_views);
+                } else {
+                    P.arrive_per_view = 0;
+                    P.n_arrive = (unsigned)grid_wgs;
+                }
+            }
+        }
+    }
     if (stats && !(d->flags & RNR_CONV_STATS_PREZEROED)) {
         // (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph went stale on replay, raster.hip)
         const long n = (long)num_views * d->c_out_pad * 2;
         hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, stats, n);
     }
-    if (pl.splitk > 1) {
+    if (combine) {
+        RNR_REQUIRE(workspace && workspace_bytes >= combine_slab_floats(pl) * sizeof(float),
+                    "rnr_conv2d: workspace too small (%zu < %zu)", workspace_bytes, combine_slab_floats(pl) * sizeof(float));
+        P.slabs = reinterpret_cast<float*>(workspace);
+        P.out = out_raw;
+        P.slab_stride = 0;
+    } else if (pl.splitk > 1) {
         RNR_REQUIRE(workspace && workspace_bytes >= (size_t)pl.splitk * out_floats * sizeof(float),
                     "rnr_conv2d: workspace too small (%zu < %zu)", workspace_bytes,
                     (size_t)pl.splitk * out_floats * sizeof(float));
@@ -1673,7 +1972,7 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
     const bool emu = (d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && (d->kind != RNR_CONV4x4S2_REFLECT || pl.cfg == 2);
     if (emu) {
         P.weight_emu = weight_packed + packed_f32_floats(d);
-        const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
+        const dim3 grid((unsigned)grid_wgs);
         const bool f16 = (d->flags & RNR_CONV_F32_EMU_F16X3) != 0;
         if (d->kind == RNR_CONV4x4S2_REFLECT) { if (f16) launch_halo_emu<1, 1>(pl, grid, P, st); else launch_halo_emu<0, 1>(pl, grid, P, st); }
         else if (d->kind == RNR_CONV3x3_REFLECT) { if (f16) launch_halo_emu<1, 0>(pl, grid, P, st); else launch_halo_emu<0, 0>(pl, grid, P, st); }
@@ -1686,14 +1985,42 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
     else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_kind<1>(pl, P, st);
     else launch_kind<2>(pl, P, st);
     if (int e = check_launch("conv_mfma_kernel")) return e;
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !combine) {
         const long rows = (long)num_views * pl.OH * pl.OW;
         const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)((d->c_out_pad + 63) / 64));
         hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, reinterpret_cast<const float*>(workspace),
-                           (long)out_floats, pl.splitk, out_raw, stats, rows, pl.OH * pl.OW, d->c_out, d->c_out_pad);
+                           (long)out_floats, pl.splitk, out_raw, rows, pl.OH * pl.OW, P);
         if (int e = check_launch("splitk_reduce_kernel")) return e;
     }
+    if (with_bn && !in_kernel_bn) {
+        hipLaunchKernelGGL(bn_finalize_shards_kernel, dim3((unsigned)num_views), dim3(CTHREADS), 0, st, P);
+        if (int e = check_launch("bn_finalize_shards_kernel")) return e;
+    }
     return 0;
+}
+
+extern "C" int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                          const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
+                          int in_w, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_run(d, src0, src1, weight_packed, out_raw, stats, nullptr, nullptr, 0, num_views, in_h, in_w, workspace,
+                      workspace_bytes, nullptr, stream);
+}
+
+extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                                 const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h,
+                                 int in_w, void* workspace, size_t workspace_bytes, const uint8_t* tile_mask,
+                                 void* stream) {
+    return conv2d_run(d, src0, src1, weight_packed, out_raw, stats, nullptr, nullptr, 0, num_views, in_h, in_w, workspace,
+                      workspace_bytes, tile_mask, stream);
+}
+
+extern "C" int rnr_conv2d_fused(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                                const float* weight_packed, float* out_raw, const rnr_conv_bn* bn, int num_views, int in_h,
+                                int in_w, void* workspace, size_t workspace_bytes, void* sync, size_t sync_bytes,
+                                const uint8_t* tile_mask, void* stream) {
+    RNR_REQUIRE(sync, "rnr_conv2d_fused: null sync buffer");
+    return conv2d_run(d, src0, src1, weight_packed, out_raw, nullptr, bn, sync, sync_bytes, num_views, in_h, in_w, workspace,
+                      workspace_bytes, tile_mask, stream);
 }
 
 static int bn_finalize_impl(double* stats, const float* gamma, const float* beta, float* scale, float* shift,

@@ -44,6 +44,10 @@ class RnrConvDesc(ctypes.Structure):
                 ('c_out', c_int), ('c_out_pad', c_int), ('flags', c_int)]
 
 
+class RnrConvBn(ctypes.Structure):
+    _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('eps', c_float)]
+
+
 ACT_NONE, ACT_LRELU02, ACT_RELU = 0, 1, 2
 CONV_STATS_PREZEROED = 1
 CONV_F32_EMU_BF16X6 = 2
@@ -82,6 +86,9 @@ SIGNATURES = {
     'rnr_conv_active_tiles': (c_int, [P(RnrConvDesc), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_conv2d_masked': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'rnr_conv_sync_bytes': (c_size_t, [P(RnrConvDesc), c_int, c_int, c_int]),
+    'rnr_conv2d_fused': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, P(RnrConvBn), c_int, c_int,
+                                 c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     'rnr_bn_finalize': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_bn_finalize_reset': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_bn_finalize_batch': (c_int, [c_void_p] * 7 + [c_float, c_int, c_int, c_int, c_double, c_float, c_void_p]),

@@ -8,11 +8,12 @@ and ignored.  BatchNorm uses per-view batch statistics (the reference forces BN 
 test_rnr.py:229-233, with N = 1 per call); Dropout2d is the identity in eval mode.
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
-from ._lib import (ACT_LRELU02, ACT_NONE, ACT_RELU, CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2, RnrConvDesc,
+from ._lib import (ACT_LRELU02, ACT_NONE, ACT_RELU, CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2, RnrConvBn, RnrConvDesc,
                    RnrConvSrc, check)
 from .ops import _ptr, _stream, on_device
 
@@ -66,6 +67,10 @@ class UNetPlan:
         has = lambda k: (prefix + k) in sd
         self.steps = []
         self.ws_bytes = 256
+        # One launch per convolution (rnr_conv2d_fused): the BatchNorm behind it is finalised by the last workgroup of each
+        # view and shallow split-K slices meet inside the launch.  'batch_all' (whole-batch statistics, running buffers)
+        # keeps the separate rnr_bn_finalize_batch launch; RNR_UNET_UNFUSED=1 runs the separate launches everywhere (A/B).
+        self.fused = bn_mode != 'batch_all' and os.environ.get('RNR_UNET_UNFUSED') != '1'
         self._tile_mask = None
         self._keep = []
 
@@ -90,7 +95,11 @@ class UNetPlan:
                 oh, ow = s0.h * 2, s0.w * 2
             out = _Act(c_out, desc.c_out_pad, oh, ow, act)
             out.data = torch.empty(self.N, oh, ow, desc.c_out_pad, dtype=torch.float32, device=device)
-            step = {'desc': desc, 'packed': packed, 'srcs': srcs, 'out': out, 'in_hw': (s0.h, s0.w), 'bn': None}
+            step = {'desc': desc, 'packed': packed, 'srcs': srcs, 'out': out, 'in_hw': (s0.h, s0.w), 'bn': None, 'sync': None,
+                    'cbn': None}
+            if self.fused:       # arrival counters + statistics shards: zero now, left at zero by every call
+                step['sync'] = torch.zeros(self.L.rnr_conv_sync_bytes(ctypes.byref(desc), self.N, s0.h, s0.w),
+                                           dtype=torch.uint8, device=device)
             if bn_key is not None and has(bn_key + '.weight') and bn_mode == 'running':
                 gamma, beta = g(bn_key + '.weight'), g(bn_key + '.bias')
                 sc = gamma / torch.sqrt(g(bn_key + '.running_var') + 1e-5)
@@ -104,7 +113,10 @@ class UNetPlan:
                 # statistics start at zero and every rnr_bn_finalize_reset leaves them at zero: no memset per layer
                 desc.flags |= _lib.CONV_STATS_PREZEROED
                 step['bn'] = {'gamma': gamma, 'beta': beta, 'running_mean': None, 'running_var': None,
-                              'stats': torch.zeros(self.N, desc.c_out_pad, 2, dtype=torch.float64, device=device)}
+                              'stats': None if self.fused else
+                              torch.zeros(self.N, desc.c_out_pad, 2, dtype=torch.float64, device=device)}
+                if self.fused:
+                    step['cbn'] = RnrConvBn(gamma.data_ptr(), beta.data_ptr(), out.scale.data_ptr(), out.shift.data_ptr(), 1e-5)
                 if bn_mode == 'batch_all' and update_running_stats and has(bn_key + '.running_mean'):
                     rm, rv = sd[prefix + bn_key + '.running_mean'], sd[prefix + bn_key + '.running_var']
                     if not (rm.is_cuda and rm.dtype == torch.float32 and rm.is_contiguous() and
@@ -204,8 +216,10 @@ class UNetPlan:
             self._run_steps(n, mask, L, st)
         except Exception:
             for s in self.steps:            # a failed launch may leave statistics half-accumulated: restore the invariant
-                if s['bn']:
+                if s['bn'] and s['bn']['stats'] is not None:
                     s['bn']['stats'].zero_()
+                if s['sync'] is not None:
+                    s['sync'].zero_()
             raise
         return self.out.data[:n]
 
@@ -217,6 +231,12 @@ class UNetPlan:
             s1 = self._src(srcs[1], n) if len(srcs) > 1 else None
             out, bn = s['out'], s['bn']
             h, w = s['in_hw']
+            if self.fused:
+                check(L.rnr_conv2d_fused(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
+                                         _ptr(s['packed']), _ptr(out.data), ctypes.byref(s['cbn']) if s['cbn'] else None, n, h, w,
+                                         _ptr(self.workspace), self.ws_bytes, _ptr(s['sync']), s['sync'].numel(),
+                                         _ptr(mask) if s is last else None, st))
+                continue
             check(L.rnr_conv2d_masked(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
                                       _ptr(s['packed']), _ptr(out.data), _ptr(bn['stats']) if bn else None, n, h, w,
                                       _ptr(self.workspace), self.ws_bytes, _ptr(mask) if s is last else None, st))

@@ -19,7 +19,7 @@ from rnr_amd.ops import _ptr, _stream  # noqa: E402
 DEV = torch.device('cuda:0')
 
 
-def time_layer(L, idx, kind, H, cins, cout, V, flags, iters, stats_on=True, zero=''):
+def time_layer(L, idx, kind, H, cins, cout, V, flags, iters, stats_on=True, zero='', unfused=False):
     pad16 = lambda c: (c + 15) // 16 * 16
     keep, csrc = [], []
     for j, C in enumerate(cins):
@@ -47,9 +47,23 @@ def time_layer(L, idx, kind, H, cins, cout, V, flags, iters, stats_on=True, zero
     wsb = L.rnr_conv_workspace_bytes(ctypes.byref(desc), V, H, H)
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=DEV)
 
+    # the product path (rnr_amd.unet.UNetPlan): rnr_conv2d_fused, BatchNorm finalised by the convolution's own launch where the
+    # network has one (layers 10-13 and 22 carry a bias instead); --unfused times the legacy rnr_conv2d (statistics only)
+    has_bn = stats_on and idx not in (10, 11, 12, 13, 22)
+    sync = torch.zeros(L.rnr_conv_sync_bytes(ctypes.byref(desc), V, H, H), dtype=torch.uint8, device=DEV)
+    gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV)
+    scale, shift = torch.empty(V, desc.c_out_pad, device=DEV), torch.empty(V, desc.c_out_pad, device=DEV)
+    cbn = _lib.RnrConvBn(gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), 1e-5)
+    keep += [sync, gamma, beta, scale, shift]
+
     def call():
-        _lib.check(L.rnr_conv2d(ctypes.byref(desc), ctypes.byref(csrc[0]), ctypes.byref(csrc[1]) if len(csrc) > 1 else None,
-                                _ptr(packed), _ptr(out), _ptr(stats) if stats_on else None, V, H, H, _ptr(ws), wsb, _stream()))
+        if unfused:
+            _lib.check(L.rnr_conv2d(ctypes.byref(desc), ctypes.byref(csrc[0]), ctypes.byref(csrc[1]) if len(csrc) > 1 else None,
+                                    _ptr(packed), _ptr(out), _ptr(stats) if stats_on else None, V, H, H, _ptr(ws), wsb, _stream()))
+        else:
+            _lib.check(L.rnr_conv2d_fused(ctypes.byref(desc), ctypes.byref(csrc[0]), ctypes.byref(csrc[1]) if len(csrc) > 1 else None,
+                                          _ptr(packed), _ptr(out), ctypes.byref(cbn) if has_bn else None, V, H, H, _ptr(ws), wsb,
+                                          _ptr(sync), sync.numel(), None, _stream()))
     for _ in range(3):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,6 +85,7 @@ def main():
     ap.add_argument('--layers', default='')
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--no-stats', action='store_true')
+    ap.add_argument('--unfused', action='store_true', help='legacy rnr_conv2d (separate split-K reduce, no BatchNorm finalise)')
     ap.add_argument('--zero', default='', help="'w' zero weights, 'a' zero activations, 'wa' both: data-dependent power")
     a = ap.parse_args()
     L = _lib.load()
@@ -81,7 +96,7 @@ def main():
     for idx, kind, H, cins, cout in LAYERS:
         if idx not in want:
             continue
-        us, fl = time_layer(L, idx, kind, H, cins, cout, a.views, flags, a.iters, not a.no_stats, a.zero)
+        us, fl = time_layer(L, idx, kind, H, cins, cout, a.views, flags, a.iters, not a.no_stats, a.zero, a.unfused)
         tot_us += us
         tot_fl += fl
         print('L%-2d kind %d %4d^2 %-9s -> %3d  %8.1f us  %6.1f TF/s  %.3f of peak' % (
