@@ -1691,7 +1691,11 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     if (p->halo && !(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && p->bm == 128) {
         const long t128 = (long)N * (p->Ho / th) * (p->Wo / p->tw) * p->ntiles * p->par;
         const int th64 = p->tw == 32 ? 2 : 4;
-        if (t128 < RNR_SMALL_TILE_BELOW && p->Ho % th64 == 0) {
+        // (the 4x4-s2 convolution has a barrier every 4 taps: with 8 MFMAs per tap the halo fetch of the next K step is not
+        // covered any more — 64^2 -> 32^2 at one view: 95 us on 64 x 64 tiles against 88 on 128 x 128 x 16 slices — so
+        // it takes the small tiles only where the alternative is a 32-way split)
+        const int below = d->kind == RNR_CONV4x4S2_REFLECT ? RNR_SMALL_TILE_BELOW / 4 : RNR_SMALL_TILE_BELOW;
+        if (t128 < below && p->Ho % th64 == 0) {
             p->cfg = 3; p->bm = 64; p->bn = 64; th = th64;
             p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
         }

@@ -28,7 +28,7 @@ import sph_harm
 from pytorch_prototyping.pytorch_prototyping import *  # noqa: F401,F403  (the reference does the same, network.py:10)
 from pytorch_prototyping.pytorch_prototyping import Unet
 from rnr_amd import ops
-from rnr_amd.testing import ray_pivots as _ray_pivots
+from rnr_amd.rays import ray_pivots as _ray_pivots
 
 
 class TextureMapper(nn.Module):

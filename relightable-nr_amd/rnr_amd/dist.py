@@ -57,8 +57,15 @@ def render_views_sharded(render_fn, views, group=None, gather=True, frame_shape=
         if meta[7] == 0:
             return None                        # B == 0: nobody rendered anything
         tail, dtype = tuple(int(x) for x in meta[1:1 + int(meta[0])]), _DTYPE_CODES[int(meta[7]) - 1]
-    if frames is not None and (tuple(frames.shape[1:]) != tail or frames.dtype != dtype):
-        raise ValueError('rank %d renders %s %s, the group agreed on %s %s' % (rank, tuple(frames.shape[1:]), frames.dtype, tail, dtype))
+    # a rank whose frames disagree with the agreed shape / dtype must not be the only one to raise: the others would go on
+    # into the all-gather and hang.  One more small all_reduce makes the failure collective.
+    mine_bad = frames is not None and (tuple(frames.shape[1:]) != tail or frames.dtype != dtype)
+    bad = torch.tensor([1 if mine_bad else 0], dtype=torch.int64, device=_dev(views))
+    dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
+    if int(bad.item()):
+        raise ValueError('%d rank(s) render frames that differ from the agreed %s %s (rank %d renders %s)'
+                         % (int(bad.item()), tail, dtype, rank,
+                            'nothing' if frames is None else '%s %s' % (tuple(frames.shape[1:]), frames.dtype)))
     send = torch.zeros((max_b,) + tail, dtype=dtype, device=_dev(views))
     if frames is not None:
         send[:hi - lo] = frames

@@ -91,6 +91,22 @@ def _chk(t, name, dtype=torch.float32):
     return t
 
 
+_SIDE_STREAMS = {}
+
+
+def side_streams(device, n):
+    """The first `n` side HIP streams of `device`, created once per process and shared by every pipeline (view-group lanes,
+    calls in flight).  HIP multiplexes streams onto a handful of hardware queues (4 by default): a process that keeps creating
+    streams ends up with two of them on ONE queue, where their kernels run strictly one after the other — measured: the two
+    slots of RNRPipeline(inflight=2) delivered exactly the sequential rate after other pipelines had created six streams."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

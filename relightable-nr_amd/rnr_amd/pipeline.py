@@ -7,6 +7,15 @@ hand-written gfx950 kernel launched on the current HIP stream.
     -> bias + tanh + light-transport x env-map ray renderer                     (shade.hip)
 
 Views are independent (BatchNorm statistics are per view), so a batch of N poses is just N frames.
+
+Calling modes:
+    render(poses[N])                    one batch on the current stream (bench.py's headline: 8 views per call)
+    RNRPipeline(streams=k).render(..)   the batch split into k view groups on k HIP streams (kernel tails overlap)
+    RNRPipeline(inflight=d).submit(..)  the reference's mode — ONE view per call, test_rnr.py:265 — with up to d calls in
+                                        flight: call i runs on HIP stream i % d with its own G-buffer / activations, so
+                                        the rasterizer and shading kernels of view i+1 and the tails of every short
+                                        convolution launch run under the U-Net of view i.  submit() returns a FrameHandle;
+                                        handle.wait() orders the current stream behind that frame.
 """
 import numpy as np
 import torch
@@ -15,10 +24,30 @@ from . import ops
 from .unet import UNetPlan
 
 
+class FrameHandle:
+    """A frame submitted with RNRPipeline.submit: `image` [N,3,S,S] is complete once `event` has passed."""
+
+    def __init__(self, image, event):
+        self.image, self.event = image, event
+
+    def wait(self):
+        """Order the current HIP stream behind the frame (no host synchronisation) and return the image."""
+        torch.cuda.current_stream(self.image.device).wait_event(self.event)
+        return self.image
+
+    def synchronize(self):
+        self.event.synchronize()
+        return self.image
+
+
+class _Slot:
+    """Private state of one call in flight (RNRPipeline(inflight=d)): stream, U-Net activations, G-buffer, frames."""
+
+
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
                  sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10,
-                 skip_background_tiles=True, streams=1, precision='f32'):
+                 skip_background_tiles=True, streams=1, precision='f32', inflight=1):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
@@ -63,7 +92,7 @@ class RNRPipeline:
                                                    (self.S, self.S), lane_views, self.dev, share_weights_with=self.unet,
                                                    precision=precision)
                                           for _ in range(self.n_streams - 1)]
-        self._lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)] if self.n_streams > 1 else []
+        self._lane_streams = ops.side_streams(self.dev, self.n_streams) if self.n_streams > 1 else []
         self.sh_lighting, self.sh_coeff = None, None
         if sh_coeff is not None:
             from .lighting import SHLighting
@@ -86,6 +115,24 @@ class RNRPipeline:
             dt, tail = ops.GBUFFER_MAPS[m]
             self._gb[m] = torch.empty((N, S, S) + tail, dtype=dt, device=self.dev)
         self.last = {}
+        # calls in flight (submit): slot 0 is the pipeline's own state; the others share the packed weights and own the rest
+        self.inflight = max(1, int(inflight))
+        if self.inflight > 1 and self.n_streams > 1:
+            raise ValueError('streams > 1 (view groups of one batch) and inflight > 1 (several calls in flight) are exclusive')
+        self._slots, self._next_slot = [], 0
+        slot_streams = ops.side_streams(self.dev, self.inflight) if self.inflight > 1 else []
+        for i in range(self.inflight if self.inflight > 1 else 0):
+            sl = _Slot()
+            sl.stream = slot_streams[i]
+            sl.unet = self.unet if i == 0 else UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0,
+                                                        num_down, (S, S), N, self.dev, share_weights_with=self.unet,
+                                                        precision=precision)
+            sl.ws = self._lane_ws[0] if i == 0 else torch.empty_like(self._lane_ws[0])
+            sl.gb = self._gb if i == 0 else {m: torch.empty_like(t) for m, t in self._gb.items()}
+            sl.net_in = self._net_in if i == 0 else torch.empty_like(self._net_in)
+            sl.images = [torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev) for _ in range(2)]
+            sl.flip = 0
+            self._slots.append(sl)
 
     def set_light_probe(self, lp):
         lp = torch.as_tensor(lp, dtype=torch.float32)
@@ -98,6 +145,37 @@ class RNRPipeline:
         (measurement only — bench.py's per-stage HBM figures)."""
         with ops.on_device(self.dev):
             return self._render(proj, pose, proj_inv, R_inv, keep_intermediates, lighting_idx, stage_events)
+
+    def submit(self, proj, pose, proj_inv, R_inv, lighting_idx=0):
+        """One call of the reference's per-view loop (test_rnr.py:265-377), asynchronous: the poses [N <= max_views] are
+        rendered on the next of the `inflight` private HIP streams (after everything already queued on the current stream,
+        which produced the poses) and a FrameHandle is returned at once.  The image stays valid until 2 * inflight further
+        submits.  With inflight == 1 this is render() plus an event."""
+        with ops.on_device(self.dev):
+            if not self._slots:
+                image = self._render(proj, pose, proj_inv, R_inv, False, lighting_idx, None)
+                ev = torch.cuda.Event()
+                ev.record()
+                return FrameHandle(image, ev)
+            N = proj.shape[0]
+            if N > self.max_views:
+                raise RuntimeError('pipeline built for max_views=%d, got %d poses' % (self.max_views, N))
+            sl = self._slots[self._next_slot]
+            self._next_slot = (self._next_slot + 1) % len(self._slots)
+            sl.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sl.stream):
+                # per-call work of the reference inside the slot's stream too (tangents, SH light probe): every temporary
+                # is allocated, used and recycled in that stream's order
+                self.mesh._tangents = None
+                self.mesh.tangents()
+                lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
+                image = sl.images[sl.flip][:N]
+                sl.flip ^= 1
+                self._render_group(0, 0, N, proj.contiguous(), pose.contiguous(), proj_inv.contiguous(), R_inv.contiguous(),
+                                   lp, image, lambda name: None, slot=sl)
+                ev = torch.cuda.Event()
+                ev.record(sl.stream)
+            return FrameHandle(image, ev)
 
     def _render(self, proj, pose, proj_inv, R_inv, keep_intermediates, lighting_idx, stage_events):
 
@@ -140,19 +218,22 @@ class RNRPipeline:
             cur.wait_stream(st)
         return image
 
-    def _render_group(self, lane, lo, hi, proj, pose, proj_inv, R_inv, lp, image, mark):
-        """Views [lo, hi) of the batch on the current stream, with lane-private scratch and U-Net activations."""
+    def _render_group(self, lane, lo, hi, proj, pose, proj_inv, R_inv, lp, image, mark, slot=None):
+        """Views [lo, hi) of the batch on the current stream, with lane-private scratch and U-Net activations (or, for a
+        submitted call, everything private to its slot)."""
         n = hi - lo
-        unet = self._lane_unets[lane]
+        unet = self._lane_unets[lane] if slot is None else slot.unet
+        gbufs = self._gb if slot is None else slot.gb
+        net_in = self._net_in if slot is None else slot.net_in
         R = pose[lo:hi, :3, :3].contiguous()
         t = pose[lo:hi, :3, 3].contiguous()
         v_uvz = ops.project_vertices(self.mesh.v, proj[lo:hi], R, t, self.S)
-        gb = {m: self._gb[m][lo:hi] for m in self._gb_maps}
+        gb = {m: gbufs[m][lo:hi] for m in self._gb_maps}
         ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
-                              workspace=self._lane_ws[lane])
+                              workspace=self._lane_ws[lane] if slot is None else slot.ws)
         mark('raster')
         sh = ops.shade_inputs(gb, self.mesh, proj_inv[lo:hi], R_inv[lo:hi], self.textures, self.pivots_spec,
-                              self.pivots_diff, self.sh_start_ch, c_pad=unet.in_c_pad, net_in=self._net_in[lo:hi])
+                              self.pivots_diff, self.sh_start_ch, c_pad=unet.in_c_pad, net_in=net_in[lo:hi])
         mark('shade_inputs')
         raw = unet.forward(sh['net_in'], n, gb['alpha'] if self.skip_background_tiles else None)
         mark('unet')

@@ -1,5 +1,6 @@
-"""One view per call (the reference's mode, test_rnr.py:265), D calls in flight: D independent RNRPipeline(max_views=1)
-objects, each on its own HIP stream, fed round-robin.  frames/s and ms per frame for D = 1..4.
+"""One view per call (the reference's mode, test_rnr.py:265) with D calls in flight: RNRPipeline(inflight=D).submit.
+frames/s and ms per frame for D = 1..4; frames are compared with the one-call-at-a-time pipeline (bitwise apart from the
+BatchNorm statistics' atomic summation order).
 Usage (GPU box): python scripts/exp_v1_inflight.py [precision]"""
 import os
 import sys
@@ -25,27 +26,30 @@ def main():
     n, warm = 96, 8
     ids = (np.arange(n + warm) * 7) % 720
     poses = {k: torch.from_numpy(v).to(dev) for k, v in scene.spiral_views(512, ids).items()}
+    ref = None
     for D in [1, 2, 3, 4]:
-        pipes = [RNRPipeline(sc['mesh'], 512, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None,
-                             nf0=64, max_views=1, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10,
-                             skip_background_tiles=False, precision=prec) for _ in range(D)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
+        pipe = RNRPipeline(sc['mesh'], 512, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None,
+                           nf0=64, max_views=1, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10,
+                           skip_background_tiles=False, precision=prec, inflight=D)
 
         def one(s):
-            with torch.cuda.stream(streams[s % D]):
-                return pipes[s % D].render(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1],
-                                           poses['R_inv'][s:s + 1])
+            return pipe.submit(poses['proj'][s:s + 1], poses['pose'][s:s + 1], poses['proj_inv'][s:s + 1],
+                               poses['R_inv'][s:s + 1])
         for s in range(warm):
             one(s)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for s in range(warm, warm + n):
-            one(s)
+        hs = [one(s) for s in range(warm, warm + n)]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print('%s  in flight %d: %.1f frames/s  %.3f ms/frame' % (prec, D, n / dt, dt / n * 1e3))
+        last = [h.image.clone() for h in hs[-D:]]
+        if ref is None:
+            ref = pipe.render(poses['proj'][warm + n - 1:warm + n], poses['pose'][warm + n - 1:warm + n],
+                              poses['proj_inv'][warm + n - 1:warm + n], poses['R_inv'][warm + n - 1:warm + n]).clone()
+        print('%s  in flight %d: %.1f frames/s  %.3f ms/frame   max |last frame - sequential| = %.2e' % (
+            prec, D, n / dt, dt / n * 1e3, float((last[-1] - ref).abs().max())))
         sys.stdout.flush()
-        del pipes
+        del pipe
 
 
 if __name__ == '__main__':

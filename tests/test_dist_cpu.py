@@ -118,3 +118,38 @@ def test_shard_bounds_properties():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_mismatch(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, 'relightable-nr_amd'))
+    from rnr_amd import dist as rdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        views = {'pose': torch.randn(4, 4, 4)}
+        # rank 1 renders half-precision frames although the caller stated float32: BOTH ranks must raise (before the fix only
+        # rank 1 did and rank 0 hung in the all-gather)
+        render = (lambda v: _fake_render(v).half()) if rank == 1 else _fake_render
+        try:
+            rdist.render_views_sharded(render, views, frame_shape=(3, 4, 4), frame_dtype=torch.float32)
+            q.put((rank, 'no error'))
+        except ValueError as e:
+            q.put((rank, 'raised: ' + str(e)[:40]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_mismatch_on_one_rank_raises_everywhere():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000) + 131
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(msg.startswith('raised') for _, msg in res), res
