@@ -100,8 +100,8 @@ def cpu_baseline(sc, args, view_id, hip_image, emu_image=None, budget_s=150.0):
     workload, BASELINE.md §3 protocol: 3 warm-up + 10 timed frames, median, one view per call like test_rnr.py:265; pose
     tensors and the view-independent lmax-10 lighting basis are prepared OUTSIDE the timer (the reference builds that
     basis once in LightingSH.__init__, network.py:574-582).  Threads: the protocol says every host core; torch-CPU's small
-    ops oversubscribe badly on a 256-thread host, so one frame is rendered at {all, 64, 32} threads first (these count as
-    warm-up frames) and the fastest setting is timed, the others are listed.  Also yields the parity figure (PSNR of the HIP
+    ops oversubscribe badly on a 256-thread host, so a quarter-resolution probe frame is rendered at {all, half, 64, 32, 16}
+    threads first and the fastest setting is timed, the others are listed.  Also yields the parity figure (PSNR of the HIP
     frame vs the oracle frame of the same pose)."""
     from oracle import rnr_oracle as orc
     from oracle import raster as oras
