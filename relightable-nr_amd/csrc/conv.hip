@@ -42,6 +42,9 @@ constexpr int CTHREADS = 256;
 #ifndef RNR_SMALL_TILE_BELOW
 #define RNR_SMALL_TILE_BELOW 128     // fewer 128 x 128 tiles than this: 64 x 64 tiles (make_plan)
 #endif
+#ifndef RNR_CFG4_MAX
+#define RNR_CFG4_MAX 512             // at most this many 128 x 128 tiles: 128 x 64 tiles instead (make_plan, 3x3 only); 0 = never
+#endif
 #ifndef RNR_FUSED_BN_MIN_WGS
 #define RNR_FUSED_BN_MIN_WGS 256     // in-kernel BatchNorm finalise for grids larger than this
 #endif
@@ -54,6 +57,12 @@ constexpr int CTHREADS = 256;
 #ifndef RNR_HALO_WAVES
 #define RNR_HALO_WAVES 3    // waves per SIMD the halo kernels are register-bounded for (4 would spill and exceed LDS anyway)
 #endif
+
+// waves per SIMD a halo-kernel configuration is register-bounded for: 128 x 64 tiles (32 accumulator registers) four, the
+// 64-accumulator tiles three (RNR_HALO_WAVES), 256 x 128 and the 80-column remainder configuration two
+constexpr int halo_waves(int WM, int WN, int R16) {
+    return R16 ? 2 : (WM * WN <= 2 ? 4 : (WM * WN <= 4 ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1)));
+}
 
 struct ConvParams {
     const float* src_data[2];
@@ -85,6 +94,7 @@ struct ConvParams {
     const float* gamma; const float* beta; float* scale; float* shift;
     float eps; double count;    // pixels per view behind one statistic
     unsigned* tile_arrive;      // [par * mtiles * ntiles] split-K slices of a tile that have published their slab; NULL = legacy slabs + reduce kernel
+    int par_inner;              // tile order of the transposed conv: parity class inside the pixel tile (see tile_coords)
     float* slabs;               // in-launch combine: [splitk][tile][wave][i][j][4 quads][64 lanes][4] accumulator images
 };
 constexpr int STAT_SHARDS = 8;  // one per XCD: at one view per call every workgroup of a layer hits the same 2 * c_out words
@@ -101,8 +111,14 @@ __device__ __forceinline__ void tile_coords(const ConvParams& P, int& mt, int& n
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     nt = id % P.ntiles;
     const int t = id / P.ntiles;
-    mt = t % P.mtiles;
-    z = t / P.mtiles;
+    if (P.par_inner) {      // transposed conv: the four output-parity classes of a pixel tile are neighbours (they stage the SAME input halo)
+        const int t2 = t >> 2;
+        mt = t2 % P.mtiles;
+        z = (t2 / P.mtiles) * 4 + (t & 3);
+    } else {
+        mt = t % P.mtiles;
+        z = t / P.mtiles;
+    }
 }
 
 __device__ __forceinline__ int reflect1(int i, int n) {   // ReflectionPad2d(1)
@@ -592,7 +608,7 @@ __device__ __forceinline__ void store_acc_tiles(const ConvParams& P, float* out,
 }
 
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW>
-__global__ void __launch_bounds__(CTHREADS, (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
+__global__ void __launch_bounds__(CTHREADS, halo_waves(WM, WN, R16))
 conv_halo_kernel(const ConvParams P) {
     // TW = 32: a 32-row MFMA block is one image row of the tile; TW = 16 (maps 16 pixels wide): two image rows
     static_assert(TW == 32 || (TW == 16 && !R16), "tile width");
@@ -987,7 +1003,7 @@ __device__ __forceinline__ void tile_coords_of(const ConvParams& P, int b, int& 
 }
 
 template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW>
-__global__ void __launch_bounds__(CTHREADS, (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1))
+__global__ void __launch_bounds__(CTHREADS, halo_waves(WM, WN, R16))
 conv_halo_persist_kernel(const ConvParams P) {
     static_assert(TW == 32 || (TW == 16 && !R16), "tile width");
     constexpr int RPB = 32 / TW;
@@ -1786,7 +1802,7 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
     constexpr size_t lds_red = (size_t)(WAVES_M * BN * 2) * sizeof(float);         // statistics reduction of the epilogue
     constexpr size_t lds_min = lds_halo > lds_red ? lds_halo : lds_red;
     // workgroups per CU the registers allow (the kernel's __launch_bounds__) and LDS allows
-    constexpr int nat = (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1);
+    constexpr int nat = halo_waves(WM, WN, R16);
     constexpr int lds_slots = (int)((160 * 1024) / lds_min);
     const int slots = balanced_slots((long)grid.x, nat < lds_slots ? nat : lds_slots);
     // fewer co-resident workgroups are requested by padding the dynamic LDS allocation
@@ -1810,7 +1826,7 @@ static bool launch_halo_persist_cfg(long total, const ConvParams& P, hipStream_t
     constexpr int TH = WAVES_M * WM * (32 / TW), BN = WAVES_N * (WN * 32 + R16 * 16);
     constexpr int HP = (KIND == 1 ? TW + 1 : TW + 2) * (KIND == 1 ? TH + 1 : TH + 2);
     constexpr size_t lds_min = (size_t)(2 * BK * HP) * sizeof(float) + (size_t)BN * 2 * sizeof(double) + 16;
-    constexpr int nat = (WM * WN <= 4 && !R16) ? RNR_HALO_WAVES : (WM * WN <= 8 ? 2 : 1);
+    constexpr int nat = halo_waves(WM, WN, R16);
     constexpr int lds_slots = (int)((160 * 1024) / lds_min);
     const int slots = balanced_slots(total, nat < lds_slots ? nat : lds_slots);
     const long G = 256L * slots;                    // a multiple of 8: workgroup w and its tiles w + i G share an XCD
@@ -2141,6 +2157,18 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
             p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
         }
     }
+    // ... and mid-size maps (one view per call: 256 - 512 tiles of 128 x 128, i.e. one or two workgroups = waves per SIMD):
+    // 128 x 64 tiles (32 x 4 pixels, 64 columns; 32 accumulator registers, four waves per SIMD) double the tile count
+    static const int cfg4_max = [] { const char* e = getenv("RNR_CFG4_MAX"); return e ? atoi(e) : RNR_CFG4_MAX; }();
+    // (3x3 only: measured at one view per call 154 -> 149 us at 128^2 and 159 -> 154 at 64^2, but the stride-2 and transposed
+    // convolutions — four taps per barrier — lose 3 - 18 us with half the MFMAs per tap)
+    if (p->halo && d->kind == RNR_CONV3x3_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 2 && p->bm == 128 && p->tw == 32) {
+        const long t128 = (long)N * (p->Ho / th) * (p->Wo / p->tw) * p->ntiles * p->par;
+        if (t128 <= cfg4_max && t128 >= RNR_SMALL_TILE_BELOW) {
+            p->cfg = 4; p->bm = 128; p->bn = 64;
+            p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
+        }
+    }
     // the halo kernels address a view with 32-bit element offsets
     const long view_elems = (long)H * W * (d->c_in0_pad > d->c_in1_pad ? d->c_in0_pad : d->c_in1_pad);
     if (view_elems >= (1L << 30)) p->halo = 0;
@@ -2193,7 +2221,8 @@ static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st)
         if (pl.cfg == 2 && pl.bm == 128 && launch_halo_persist_cfg<KIND, 2, 2, 2, 2, 0>(total, P, st)) return;
     }
 #endif
-    if (pl.cfg == 3 && pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 1, 1, 0, 16>(grid, P, st);      // 16 x 4 pixel tiles, 64 columns
+    if (pl.cfg == 4) launch_halo_cfg<KIND, 4, 1, 1, 2, 0>(grid, P, st);                         // 32 x 4 pixel tiles, 64 columns
+    else if (pl.cfg == 3 && pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 1, 1, 0, 16>(grid, P, st);      // 16 x 4 pixel tiles, 64 columns
     else if (pl.cfg == 3) launch_halo_cfg<KIND, 2, 2, 1, 1, 0>(grid, P, st);                    // 32 x 2 pixel tiles, 64 columns
     else if (pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 2, 2, 0, 16>(grid, P, st);       // 16 x 8 pixel tiles, 128 columns
     else if (pl.cfg == 0) launch_halo_cfg<KIND, 4, 1, 2, 2, 0>(grid, P, st);
@@ -2365,6 +2394,16 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
     P.splitk = pl.splitk;
     P.mtiles = pl.mtiles; P.ntiles = pl.ntiles; P.zdim = pl.splitk * pl.par;
+    if (d->kind == RNR_CONVT4x4S2) {
+        // Each parity class is its own workgroup and stages the same input halo.  With the class as the slowest tile index the
+        // input is streamed from HBM four times (r02 PMC: 2.9x the compulsory bytes on the 64-column transposed conv); as
+        // neighbours the four share one L2.  The price is four weight sets in flight per XCD instead of one, so the order is
+        // chosen by which operand is bigger.  RNR_PAR_INNER=0/1 forces it (experiments).
+        static const int forced = [] { const char* e = getenv("RNR_PAR_INNER"); return e ? atoi(e) : -1; }();
+        const size_t w_bytes = 16 * (size_t)(d->c_in0_pad + d->c_in1_pad) * d->c_out_pad * sizeof(float);
+        const size_t in_bytes = (size_t)in_h * in_w * (d->c_in0_pad + d->c_in1_pad) * sizeof(float);     // per view
+        P.par_inner = forced >= 0 ? forced : (in_bytes >= w_bytes ? 1 : 0);
+    }
     if (tile_mask) {
         RNR_REQUIRE(!stats && !with_bn, "rnr_conv2d_masked: skipped tiles would falsify the batch statistics (no statistics / BatchNorm with a mask)");
         RNR_REQUIRE(rnr_conv_tile_count(d, num_views, in_h, in_w) > 0,
