@@ -250,7 +250,8 @@ typedef struct rnr_conv_desc {
  * v_mfma_f32_32x32x16_f16: 5.3x fewer MFMA cycles than the exact-fp32 kernel, half of bf16x6.  Measured error against a
  * float64 convolution is below the exact-fp32 kernel's on every U-Net layer shape it covers (fewer accumulator roundings outweigh
  * the two missing significand bits; tests/test_gpu_unet.py).  Weights are pre-scaled per layer by a power of two at pack
- * time (undone exactly in the epilogue), so any finite weights are fine; activations must satisfy
+ * time (2^k with |k| <= 40, undone exactly in the epilogue; a layer whose max |w| is below 2^-28 keeps fewer fp16 bits), so
+ * any finite weights are fine; activations must satisfy
  * |act(scale * x + shift)| < 65504 — true for BatchNorm outputs and bounded network inputs; values below 2^-14 keep an
  * absolute precision of 2^-25 (fp16 subnormals are honoured by the MFMA).  Same packing / fallback rules as BF16X6;
  * the two flags are mutually exclusive. */
@@ -274,6 +275,9 @@ size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views, int in_h,
  * (test_rnr.py:229-233).
  *   src0/src1: `channels` must equal c_in0_pad / c_in1_pad; src1 may be NULL when c_in1_pad == 0.
  *   out_raw [N, Ho, Wo, c_out_pad]  (Ho,Wo = H,W | H/2,W/2 | 2H,2W by kind)
+ * Reproducibility: out_raw is bit-reproducible run to run (fixed summation order, also across split-K slabs); `stats` is
+ * NOT — every workgroup adds its column sums with one float64 atomicAdd per channel, whose order varies, so the last
+ * bits of the statistics (and of everything normalised with them) may differ between runs (tests compare at 1e-5).
  */
 int rnr_conv2d(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
                const float* weight_packed, float* out_raw, double* stats, int num_views, int in_h, int in_w,

@@ -2044,7 +2044,9 @@ pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __res
         const float amax = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(image)[2]);
         if (amax > 0.0f) {
             kexp = 12 - ilogbf(amax);
-            kexp = min(max(kexp, -100), 100);
+            // +-40: the epilogue's column statistics square the SCALED accumulators before the scale is undone, and 2^80
+            // times a squared activation sum still fits fp32; weights below 2^-28 simply keep fewer fp16 bits
+            kexp = min(max(kexp, -40), 40);
         }
         wscale = ldexpf(1.0f, kexp);
     }

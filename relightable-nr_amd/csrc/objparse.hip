@@ -13,6 +13,8 @@
 // Faces must be triangles (the reference's np.vstack + downstream code assume [nf,3]); anything else is an error.
 #include "rnr_internal.h"
 
+#include <cmath>
+
 #include <charconv>
 #include <cstring>
 
@@ -46,19 +48,36 @@ inline void skip_line(Cursor& c) {
 }
 
 inline bool parse_float(const char* b, const char* e, float& out) {
-    if (b < e && *b == '+') b++;                 // float('+1.5') is legal Python; from_chars rejects the sign
+    if (b < e && *b == '+') {                    // float('+1.5') is legal Python; from_chars rejects the sign
+        b++;
+        if (b < e && (*b == '+' || *b == '-')) return false;           // '+-1': ValueError in Python
+    }
+    if (e > b && e[-1] == ')') return false;     // from_chars reads 'nan(chars)'; float() does not
     double d = 0.0;
     auto r = std::from_chars(b, e, d, std::chars_format::general);
-    if (r.ec != std::errc() || r.ptr != e) {
-        // inf / nan / odd spellings: let strtod decide (Python accepts 'inf', 'nan', 'Infinity')
+    if (r.ec == std::errc::result_out_of_range && r.ptr == e) {
+        // a well-formed decimal beyond double's range: float('1e400') = inf, float('1e-400') = 0.0 — strtod's answers
         char buf[64];
         const size_t n = (size_t)(e - b);
-        if (n == 0 || n >= sizeof(buf)) return false;
+        if (n >= sizeof(buf)) return false;
         memcpy(buf, b, n);
         buf[n] = 0;
-        char* endp = nullptr;
-        d = strtod(buf, &endp);
-        if (endp != buf + n) return false;
+        d = strtod(buf, nullptr);
+    } else if (r.ec != std::errc() || r.ptr != e) {
+        // What else Python's float() takes: [sign] inf | infinity | nan, any case.  Nothing more — strtod would also accept
+        // hexadecimal ('0x10' -> 16.0) and 'nan(...)' where the reference parser (load_obj.py:120-135, float()) raises
+        // ValueError.  Known deviations: Python's underscore literals ('1_0') and non-ASCII digits are rejected here.
+        const char* q = b;
+        bool neg = false;
+        if (q < e && *q == '-') { neg = true; q++; }      // (a leading '+' was consumed above)
+        char w[9];
+        const size_t n = (size_t)(e - q);
+        if (n == 0 || n > 8) return false;
+        for (size_t i = 0; i < n; i++) w[i] = (char)(q[i] | 0x20);
+        w[n] = 0;
+        if (!strcmp(w, "inf") || !strcmp(w, "infinity")) d = neg ? -HUGE_VAL : HUGE_VAL;
+        else if (!strcmp(w, "nan")) d = nan("");
+        else return false;
     }
     out = (float)d;
     return true;

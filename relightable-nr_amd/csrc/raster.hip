@@ -5,20 +5,25 @@
 //   forward_texture_sampling_cuda_kernel    rasterize_cuda_kernel.cu:171-242
 // and, in the fused entry point, the torch glue of network.Rasterizer.forward (network.py:156-214).
 //
-// Design (DESIGN.md §Rasterizer):
+// Design (DESIGN.md §3.1):
 //   1. face_setup_kernel, one lane per (view, face): back-face predicate, the 3x3 barycentric inverse
 //      (same IEEE binary32 operation sequence as the reference, this file is built with
 //      -ffp-contract=off), and a conservative pixel bounding box.  Faces whose box cannot be trusted
 //      (degenerate / sliver / non-finite) are flagged and decided by the exact tile test below.
-//   2. raster_tile_kernel, one 256-thread workgroup per 16x16-pixel tile: the workgroup scans the face
-//      boxes in ascending face order (8 B per face, coalesced), keeps the faces that can possibly pass
-//      the reference's inside test somewhere in the tile (exact, rounding-monotone tile test), compacts
-//      them IN ORDER into an LDS queue with wave ballots, and every lane (= pixel) then evaluates the
-//      reference's per-candidate arithmetic on LDS-broadcast face records.  Ascending order + strict `<`
-//      gives the reference's winner (first face with the smallest zp), so face_index_map, weight_map and
-//      depth_map are bit-identical to the reference evaluated without FMA contraction.
-//   3. epilogue: either the extension's maps (drop-in mode) or the perspective-corrected attribute
-//      interpolation of network.py:176-214 written once, already vertically flipped.
+//   2. splat_faces_kernel, one lane per (view, face) (near >= 0, the product path): a face whose trusted box
+//      covers <= 256 pixels walks them itself and folds (depth bits, face index) into a per-pixel 64-bit key
+//      with one atomicMin; a bigger trusted box is binned into the 16x16-pixel tiles it touches (exact,
+//      rounding-monotone tile test); untrusted boxes and huge faces go to a per-view wide list, which
+//      bin_wide_kernel tests against every tile.  (near < 0: bin_faces_kernel bins everything.)
+//   3. raster_tile_kernel, one 256-thread workgroup per tile: evaluates the reference's per-candidate
+//      arithmetic for its binned candidates on LDS-broadcast face records — unordered lists, so the
+//      reference's "ascending faces, strict <" rule is applied in its order-free form (smallest zp, ties ->
+//      smallest face index) — merges the winner with the pixel's key, and writes either the extension's maps
+//      (drop-in mode) or the perspective-corrected attribute interpolation of network.py:176-214, already
+//      vertically flipped.  A tile whose list overflowed rescans every face box itself (the in-order ballot
+//      scan of round 1, kept as the fallback: capacity never changes results).
+//   face_index_map, weight_map and depth_map are bit-identical to the reference evaluated without FMA
+//   contraction (tests/test_gpu_raster.py, tests/golden/raster_*.npz).
 #include "rnr_internal.h"
 
 namespace rnr {
@@ -274,20 +279,33 @@ constexpr unsigned long long KEY_EMPTY = ~0ull;
 
 __global__ void __launch_bounds__(256)
 splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ faces_inv, const FaceBox* __restrict__ boxes,
-                   unsigned long long* __restrict__ keys, int* __restrict__ wide_count, int* __restrict__ wide_list,
-                   int batch, int nf, int is, float near_, float far_) {
+                   unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
+                   int* __restrict__ wide_count, int* __restrict__ wide_list, int batch, int nf, int is, float near_, float far_) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)batch * nf) return;
     const int bn = (int)(i / nf), fn = (int)(i % nf);
     const FaceBox b = boxes[i];
     if (b.xlo != BOX_EXACT && b.xlo > b.xhi) return;                    // empty_box(): culled / off-screen
     const int xa = max((int)b.xlo, 0), xb = b.xhi, ya = max((int)b.ylo, 0), yb = b.yhi;
+    const float* f = faces + i * 9;
     if (b.xlo == BOX_EXACT || (xb - xa + 1) * (yb - ya + 1) > SPLAT_MAX_PIX) {
+        // too big to walk pixel by pixel.  A trusted box over a few tiles is binned right here (bin_faces_kernel's loop);
+        // only untrusted boxes and huge faces take the wide list, whose (face, tile) pairs bin_wide_kernel tests against
+        // EVERY tile — with every > 256-pixel face on it, a close-up of a coarse mesh cost wide x tiles pair tests
+        const int tiles_x = (is + TILE - 1) / TILE;
+        const int txa = xa / TILE, txb = xb / TILE, tya = ya / TILE, tyb = yb / TILE;
+        if (b.xlo != BOX_EXACT && (txb - txa + 1) * (tyb - tya + 1) <= WIDE_TILES) {
+            int* tc = tile_count + (size_t)bn * tiles_x * tiles_x;
+            int* tl = tile_list + (size_t)bn * tiles_x * tiles_x * BIN_CAP;
+            for (int ty = tya; ty <= tyb; ty++)
+                for (int tx = txa; tx <= txb; tx++)
+                    if (face_may_touch_tile(f, tx, ty, is)) bin_append(tc, tl, ty * tiles_x + tx, fn);
+            return;
+        }
         const int pos = atomicAdd(wide_count + bn, 1);
         wide_list[(size_t)bn * nf + pos] = fn;
         return;
     }
-    const float* f = faces + i * 9;
     const float* fi = faces_inv + i * 9;
     const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
     const float4 r0 = make_float4(x0, y0, x1, y1);
@@ -670,7 +688,7 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
     }
     if (splat) {
         hipLaunchKernelGGL(splat_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, faces_inv, boxes,
-                           keys, wide_count, wide_list, batch, nf, is, P->near_, P->far_);
+                           keys, tile_count, tile_list, wide_count, wide_list, batch, nf, is, P->near_, P->far_);
         if (int e = check_launch("splat_faces_kernel")) return e;
         P->keys = keys;
     } else {

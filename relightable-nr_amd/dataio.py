@@ -136,9 +136,11 @@ def _read_radiance_hdr(fp):
 
 class LightProbeDataset():
     """dataio.py:262-311 without cv2: items are {'lp_img': float32 tensor [3,H,W], RGB, ** img_gamma}.  Readers: Radiance
-    `.hdr` (numpy RGBE decoder), `.npy` ([H,W,3] float RGB), 8-bit `.png/.jpg/.jpeg` via PIL (/255).  OpenEXR needs a
-    codec this image does not ship: convert such probes to .hdr or .npy."""
-    _EXT = ('.png', '.jpg', '.jpeg', '.JPG', '.JPEG', '.hdr', '.exr', '.npy')
+    `.hdr` (numpy RGBE decoder), `.npy` ([H,W,3] float RGB), 8-bit `.png/.jpg/.JPEG/.bmp` via PIL (/255).  `.exr` / `.mat`
+    files are LISTED (they take part in the order) but raise when read: they need a codec this image does not ship."""
+    # data_util.glob_imgs' list (data_util.py:57), case-sensitive like glob, so that the sorted order — which lighting_idx
+    # indexes — is the reference's; '.npy' is this build's extra (a probe the reference could not list)
+    _EXT = ('.png', '.jpg', '.JPEG', '.bmp', '.exr', '.hdr', '.mat', '.npy')
 
     def __init__(self, data_dir, img_gamma=1.0):
         self.data_dir, self.img_gamma = data_dir, img_gamma
@@ -156,11 +158,15 @@ class LightProbeDataset():
             img = _read_radiance_hdr(fp)
         elif ext == '.npy':
             img = np.load(fp).astype(np.float32)[:, :, :3]
-        elif ext == '.exr':
-            raise NotImplementedError('%s: OpenEXR needs cv2 / OpenEXR, absent here - convert the probe to .hdr or .npy' % fp)
+        elif ext in ('.exr', '.mat'):
+            raise NotImplementedError('%s: %s probes need a codec this image does not ship (cv2 / OpenEXR / the reference\'s own '
+                                      '.mat convention) - convert the probe to .hdr or .npy' % (fp, ext))
         else:
             from PIL import Image
-            img = np.asarray(Image.open(fp).convert('RGB'), np.float32) / 255.0
+            im = Image.open(fp)
+            if im.mode not in ('RGB', 'RGBA', 'L', 'P'):       # 16-bit / float images: cv2.IMREAD_UNCHANGED keeps their range, /255 here would not
+                raise NotImplementedError('%s: %s-mode image; only 8-bit probes are read here - convert to .hdr or .npy' % (fp, im.mode))
+            img = np.asarray(im.convert('RGB'), np.float32) / 255.0
         img = np.ascontiguousarray(img.transpose(2, 0, 1)) ** self.img_gamma
         self.lp_all[idx] = {'lp_img': torch.from_numpy(img.astype(np.float32))}
 

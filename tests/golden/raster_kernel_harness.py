@@ -115,10 +115,14 @@ _libs = {}
 FLAGS = {False: ['-ffp-contract=off'], True: ['-ffp-contract=fast', '-mfma']}
 
 
-def build(fma=False):
+CLANGXX = '/opt/rocm/lib/llvm/bin/clang++'     # LLVM, like nvcc's NVVM back end: its contraction pattern is the closer stand-in
+
+
+def build(fma=False, cxx='g++'):
     fma = bool(fma)
-    if fma in _libs:
-        return _libs[fma]
+    key = fma if cxx == 'g++' else (fma, cxx)
+    if key in _libs:
+        return _libs[key]
     tmp = tempfile.mkdtemp(prefix='rnr_ref_kernels_')
     with open(REF_CU) as fh:
         body = fh.readlines()[FIRST - 1:LAST]
@@ -128,22 +132,22 @@ def build(fma=False):
         fh.writelines(body)
         fh.write(_SHIM_TAIL)
     so = os.path.join(tmp, 'ref_kernels.so')
-    subprocess.check_call(['g++', '-O2'] + FLAGS[fma] + ['-fopenmp', '-shared', '-fPIC', '-w', src, '-o', so])
+    subprocess.check_call([cxx, '-O2'] + FLAGS[fma] + ['-fopenmp', '-shared', '-fPIC', '-w', src, '-o', so])
     if fma:
         # the build must really contain fused multiply-adds, otherwise the comparison proves nothing
         dis = subprocess.run(['objdump', '-d', so], capture_output=True, text=True).stdout
         assert 'vfmadd' in dis or 'vfnmadd' in dis or 'vfmsub' in dis, 'FMA build holds no fused instruction'
-    _libs[fma] = ctypes.CDLL(so)
-    return _libs[fma]
+    _libs[key] = ctypes.CDLL(so)
+    return _libs[key]
 
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def face_index_map(faces, image_size, near, far, return_depth=1, fma=False):
+def face_index_map(faces, image_size, near, far, return_depth=1, fma=False, cxx='g++'):
     """faces [B,nf,3,3] float32 -> dict of the kernel outputs (UNFLIPPED, as the extension returns)."""
-    lib = build(fma)
+    lib = build(fma, cxx)
     faces = np.ascontiguousarray(faces, np.float32)
     B, nf = faces.shape[:2]
     S = image_size

@@ -111,6 +111,34 @@ def test_native_obj_reader_errors_and_absent_attributes(tmp_path):
         parse_obj_bytes(b"v 0 0 0\nvt 0 0\nf 1 1 1\n")
 
 
+def test_native_obj_number_grammar_is_pythons_float():
+    """The reference parser converts coordinates with float() (load_obj.py:120-135): the native reader accepts the same
+    spellings with the same values and rejects what float() rejects — hexadecimal, 'nan(...)', doubled signs (strtod, the
+    fallback of r02, took those).  Documented deviations: underscore literals ('1_0') and non-ASCII digits are rejected."""
+    from neural_renderer.load_obj import parse_obj_bytes
+    toks = ['0x10', 'inf', '-Infinity', 'NaN', '+1.5', '-2e3', '.5', '+-1', 'nan(1)', '-inf', '+inf', '+nan', '1e400', '-1e400',
+            '1e-400', '1.', '-.5e-3', 'infinit', '--1', '+', '1e', 'e5', '0x1p3', '1.5f', 'INF', 'iNfInItY', '1,5']
+    for t in toks:
+        try:
+            want = np.float32(float(t))
+        except ValueError:
+            want = None
+        try:
+            v = parse_obj_bytes(('v %s 2 3\n' % t).encode('utf-8'))[0]
+            got = v[0, 0]
+        except ValueError:
+            got = None
+        if want is None:
+            assert got is None, (t, got)
+        else:
+            assert got is not None and (got == want or (np.isnan(got) and np.isnan(want))), (t, got, want)
+            assert np.signbit(got) == np.signbit(want) or np.isnan(want), t
+    with pytest.raises(ValueError):
+        parse_obj_bytes(b'v 1_0 2 3\n')             # float('1_0') == 10.0 in Python: the documented deviation
+    with pytest.raises(ValueError):
+        parse_obj_bytes('v \u0661 2 3\n'.encode('utf-8'))   # float('\u0661') == 1.0 (Arabic-Indic digit): likewise
+
+
 def test_module_function_names():
     import camera, misc, render, sph_harm, network
     for mod, names in [(camera, ['get_view_dir_map', 'get_reflect_dir', 'RT_from_pos_lookat', 'get_spiral']),

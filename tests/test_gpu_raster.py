@@ -149,6 +149,32 @@ def test_sphere_512_vs_oracle():
     assert 0.4 < cov < 0.7
 
 
+def test_coarse_mesh_close_up_vs_oracle():
+    """Faces far larger than 16 x 16 pixels (a 12 x 24 UV sphere filling a 512^2 image, plus a soup of mid-size triangles):
+    every trusted box above 256 pixels is binned by splat_faces_kernel itself, only untrusted / huge faces take the wide
+    list (before, all of them did and were tested against every tile).  Bit-exact like everything else."""
+    from oracle import raster as oras
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    mesh = scene.uv_sphere(12, 24)
+    v = scene.spiral_views(512, [5, 300], radius=1.9)
+    uvz = orc.projection(torch.from_numpy(mesh['v'])[None], torch.from_numpy(v['proj']), torch.from_numpy(v['pose'][:, :3, :3]),
+                         torch.from_numpy(v['pose'][:, :3, 3])[:, None, :], torch.zeros(2, 5), 512)
+    faces = orc.gather_faces(uvz, torch.from_numpy(mesh['f_v_idx'])[None]).numpy()
+    g = oras.face_index_map(faces, 512, 0.0, 1e5)
+    r = run_hip_raster(faces, 512, 0.0, 1e5)
+    assert_same(r, g)
+    assert (g['face_index_map'] >= 0).mean() > 0.5
+    rng = np.random.RandomState(21)
+    f = rng.uniform(-1.2, 1.2, size=(1, 400, 3, 3)).astype(np.float32)
+    c = f[:, :, :1, :2].copy()
+    f[..., :2] = c + (f[..., :2] - c) * rng.uniform(0.05, 0.6, size=(1, 400, 1, 1)).astype(np.float32)   # 20 ... 300 px across
+    f[..., 2] = rng.uniform(0.5, 5.0, size=(1, 400, 3))
+    g = oras.face_index_map(f, 384, 0.0, 1e5)
+    r = run_hip_raster(f, 384, 0.0, 1e5)
+    assert_same(r, g)
+
+
 def test_dense_mesh_subpixel_faces_vs_oracle():
     """409 600 faces at 256^2: faces far smaller than a pixel, > 1000 candidates per 16x16 tile and list overflow at the
     poles (the scan fallback) in the same image; batch of two views.  Still bit-exact."""
