@@ -100,8 +100,8 @@ def cpu_baseline(sc, args, view_id, hip_image, emu_image=None, budget_s=150.0):
     workload, BASELINE.md §3 protocol: 3 warm-up + 10 timed frames, median, one view per call like test_rnr.py:265; pose
     tensors and the view-independent lmax-10 lighting basis are prepared OUTSIDE the timer (the reference builds that
     basis once in LightingSH.__init__, network.py:574-582).  Threads: the protocol says every host core; torch-CPU's small
-    ops oversubscribe badly on a 256-thread host, so a quarter-resolution probe frame is rendered at {all, half, 64, 32, 16}
-    threads first and the fastest setting is timed, the others are listed.  Also yields the parity figure (PSNR of the HIP
+    ops oversubscribe badly on a 256-thread host (116 s per frame, measured once), so a quarter-resolution probe frame is
+    rendered at {64, 32, 16, 8} threads first and the fastest setting is timed, the others are listed.  Also yields the parity figure (PSNR of the HIP
     frame vs the oracle frame of the same pose)."""
     from oracle import rnr_oracle as orc
     from oracle import raster as oras
@@ -132,7 +132,8 @@ def cpu_baseline(sc, args, view_id, hip_image, emu_image=None, budget_s=150.0):
     # CPUs of the r03 box took 116 s (4.8 s on 32 threads) — oversubscription of torch-CPU's small ops, not a baseline
     probe = {k: torch.from_numpy(v) for k, v in scene.spiral_views(args.img_size // 4, [view_id]).items()}
     sweep = {}
-    for n in sorted({ncpu, max(1, ncpu // 2), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    # (all 256 logical CPUs: 81 s for the PROBE frame, 116 s for a full one, measured once in r03 and not repeated on every run)
+    for n in sorted({min(ncpu, 64), min(ncpu, 32), min(ncpu, 16), min(ncpu, 8)}, reverse=True):
         set_threads(n)
         t0 = time.time()
         lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]
@@ -160,9 +161,10 @@ def cpu_baseline(sc, args, view_id, hip_image, emu_image=None, budget_s=150.0):
                      'out), same scene/weights as the GPU run, one view per call like test_rnr.py:265.  kind "port": the oracle '
                      '(OpenMP C rasterizer + torch-CPU fp32 shading / U-Net) executes the LIVE 428.7 GFLOP of the U-Net only, '
                      'whereas the reference also runs a dead 928.8 GFLOP GCN pass per frame (1357 in total, '
-                     'pytorch_prototyping.py:407-422).  %d threads = the fastest of a sweep over {all host cores, half, 64, 32, 16} on a '
-                     'quarter-resolution probe frame (all cores oversubscribe torch-CPU: 116 s per full frame measured on 256 '
-                     'threads); pose tensors and the lmax-10 lighting basis prepared outside the timer'
+                     'pytorch_prototyping.py:407-422).  %d threads = the fastest of a sweep over {64, 32, 16, 8} on a quarter-resolution '
+                     'probe frame; BASELINE.md §3\'s "all host cores" oversubscribes torch-CPU on this host (256 threads: 116 s per '
+                     'full frame, 81 s per probe frame, measured once in r03); pose tensors and the lmax-10 lighting basis prepared '
+                     'outside the timer'
                      % (len(times), args.img_size, args.img_size, int(budget_s), cores)}
     parity = None
     if hip_image is not None:

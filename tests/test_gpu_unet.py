@@ -58,6 +58,112 @@ def run_conv(kind, srcs, weight, c_out, N, H, W, flags=0):
     return out.cpu(), stats.cpu()
 
 
+def run_conv_fused(kind, srcs, weight, c_out, N, H, W, gamma=None, beta=None, flags=0, repeats=1):
+    """The product entry point rnr_conv2d_fused (one launch: convolution + BatchNorm finalise + shallow split-K combine).
+    Returns (out_raw, scale, shift, sync buffer) as CPU tensors; `repeats` > 1 re-runs the call on the same sync buffer."""
+    from rnr_amd import _lib
+    from rnr_amd.ops import _ptr, _stream
+    L = _lib.load()
+    pad16 = lambda c: (c + 15) // 16 * 16
+    keep, csrc, cs = [], [], []
+    for raw, sc, sh, act in srcs:
+        C = raw.shape[1]
+        cp = pad16(C)
+        d = torch.zeros(N, H, W, cp)
+        d[..., :C] = raw.permute(0, 2, 3, 1)
+        d = d.to(DEV)
+        scd = shd = None
+        if sc is not None:
+            scd = torch.zeros(N, cp); scd[:, :C] = sc; scd = scd.to(DEV)
+        if sh is not None:
+            shd = torch.zeros(N, cp); shd[:, :C] = sh; shd = shd.to(DEV)
+        keep += [d, scd, shd]
+        csrc.append(_lib.RnrConvSrc(d.data_ptr(), scd.data_ptr() if scd is not None else None,
+                                    shd.data_ptr() if shd is not None else None, cp, act))
+        cs.append((C, cp))
+    desc = _lib.RnrConvDesc(kind, cs[0][0], cs[0][1], cs[1][0] if len(cs) > 1 else 0, cs[1][1] if len(cs) > 1 else 0,
+                            c_out, pad16(c_out), flags)
+    packed = torch.empty(L.rnr_packed_weight_floats(ctypes.byref(desc)), device=DEV)
+    wd = weight.contiguous().to(DEV)
+    _lib.check(L.rnr_pack_conv_weight(ctypes.byref(desc), _ptr(wd), _ptr(packed), _stream()))
+    oh, ow = (H, W) if kind == 0 else ((H // 2, W // 2) if kind == 1 else (2 * H, 2 * W))
+    out = torch.full((N, oh, ow, desc.c_out_pad), float('nan'), device=DEV)
+    wsb = L.rnr_conv_workspace_bytes(ctypes.byref(desc), N, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    sync = torch.zeros(L.rnr_conv_sync_bytes(ctypes.byref(desc), N, H, W), dtype=torch.uint8, device=DEV)
+    scale = torch.full((N, desc.c_out_pad), float('nan'), device=DEV)
+    shift = torch.full((N, desc.c_out_pad), float('nan'), device=DEV)
+    cbn = None
+    if gamma is not None:
+        g, b = gamma.to(DEV), beta.to(DEV)
+        keep += [g, b]
+        cbn = _lib.RnrConvBn(g.data_ptr(), b.data_ptr(), scale.data_ptr(), shift.data_ptr(), 1e-5)
+    for _ in range(repeats):
+        _lib.check(L.rnr_conv2d_fused(ctypes.byref(desc), ctypes.byref(csrc[0]), ctypes.byref(csrc[1]) if len(csrc) > 1 else None,
+                                      _ptr(packed), _ptr(out), ctypes.byref(cbn) if cbn else None, N, H, W, _ptr(ws), wsb,
+                                      _ptr(sync), sync.numel(), None, _stream()))
+    torch.cuda.synchronize()
+    return out.cpu(), scale.cpu(), shift.cpu(), sync.cpu()
+
+
+FUSED_CASES = [
+    # kind, N, H, cins, c_out                      what the plan does at this size
+    (0, 1, 64, [512], 512),                        # 128 tiles of 128x128 -> split 4, slices meet inside the launch, tickets per tile
+    (0, 1, 32, [512], 512),                        # 64x64 tiles, split 4
+    (1, 1, 32, [512], 512),                        # 16-pixel-wide output: 64x64 tiles, deep split (reduce kernel + separate finalise)
+    (2, 1, 16, [512], 512),                        # transposed, 16 pixels wide
+    (0, 1, 128, [256], 256),                       # 128x64 tiles (four waves per SIMD)
+    (1, 1, 256, [128], 256),                       # 256 tiles of 128x128 split two ways
+    (2, 2, 64, [256, 256], 256),                   # skip concat, two views, parity classes as neighbours
+    (0, 3, 256, [64], 64),                         # 256x64 tiles, several rounds: in-kernel finalise, per-view tickets
+    (0, 2, 128, [64, 64], 78),                     # 80-column remainder configuration WITH a BatchNorm behind it
+    (0, 2, 24, [40], 24),                          # odd size: the gather kernel (one counter for the launch)
+    (1, 5, 8, [16], 16),                           # tiny maps, tiles straddle views
+]
+
+
+@pytest.mark.parametrize('kind,N,H,cins,c_out', FUSED_CASES)
+def test_conv_fused_equals_separate_launches(kind, N, H, cins, c_out):
+    """rnr_conv2d_fused == rnr_conv2d + rnr_bn_finalize: out_raw BITWISE (same plan, same summation order — also where the
+    split-K slices meet inside the launch), scale / shift to 1e-6 relative (float64 atomics arrive in any order), padded
+    channels exactly 0, and the sync buffer is all zeros again after every call (three calls in a row on one buffer)."""
+    from rnr_amd import _lib
+    from rnr_amd.ops import _ptr, _stream
+    g = torch.Generator().manual_seed(1000 * kind + 10 * H + N)
+    srcs = []
+    for j, C in enumerate(cins):
+        raw = torch.randn(N, C, H, H, generator=g)
+        sc = torch.rand(N, C, generator=g) * 0.5 + 0.75
+        sh = torch.randn(N, C, generator=g) * 0.25
+        srcs.append((raw, sc, sh, 1 if kind != 2 and j == 0 else 2))
+    cin = sum(cins)
+    k = 3 if kind == 0 else 4
+    shape = (cin, c_out, 4, 4) if kind == 2 else (c_out, cin, k, k)
+    w = (torch.rand(shape, generator=g) * 2 - 1) / (cin * k * k) ** 0.5
+    gamma = torch.rand(c_out, generator=g) + 0.5
+    beta = torch.randn(c_out, generator=g)
+    out_l, stats = run_conv(kind, srcs, w, c_out, N, H, H)
+    out_f, scale, shift, sync = run_conv_fused(kind, srcs, w, c_out, N, H, H, gamma, beta, repeats=3)
+    assert torch.equal(out_l.view(torch.int32), out_f.view(torch.int32)), 'out_raw differs between the two entry points'
+    assert int(sync.abs().max()) == 0, 'sync buffer not returned to zero'
+    L = _lib.load()
+    cp = (c_out + 15) // 16 * 16
+    oh = H if kind == 0 else (H // 2 if kind == 1 else 2 * H)
+    st = stats.to(DEV)
+    sc_l, sh_l = torch.empty(N, cp, device=DEV), torch.empty(N, cp, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    _lib.check(L.rnr_bn_finalize(_ptr(st), _ptr(gd), _ptr(bd), _ptr(sc_l), _ptr(sh_l), N, c_out, cp, float(oh * oh), 1e-5, _stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(scale[:, :c_out], sc_l.cpu()[:, :c_out], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(shift[:, :c_out], sh_l.cpu()[:, :c_out], rtol=1e-5, atol=1e-6)
+    assert float(scale[:, c_out:].abs().max() if cp > c_out else 0.0) == 0.0
+    assert float(shift[:, c_out:].abs().max() if cp > c_out else 0.0) == 0.0
+    # no BatchNorm behind the convolution: same out_raw, scale / shift untouched
+    out_n, sc_n, _, sync_n = run_conv_fused(kind, srcs, w, c_out, N, H, H)
+    assert torch.equal(out_l.view(torch.int32), out_n.view(torch.int32)) and bool(torch.isnan(sc_n).all())
+    assert int(sync_n.abs().max()) == 0
+
+
 def ref_conv(kind, srcs, weight):
     xs = []
     for raw, sc, sh, act in srcs:
