@@ -214,6 +214,22 @@ def pmc_traffic_per_step(args, views_per_step=None):
                                   '--pmc-file' % (V, args.precision)}
 
 
+def sustained_mfma_tflops():
+    """What the matrix cores SUSTAIN with random operands (scripts/micro/mfma_peak.hip: register-resident MFMA loops on every
+    SIMD, ~0.25 s per case), from the newest committed profiles/r*_mfma_peak_micro.json: {instruction: TFLOP/s} or {}.  The
+    16-bit MFMAs clock down to 1.6 - 1.8 GHz under random data (power), so the nominal 2.5 PFLOP/s is not reachable by any
+    kernel with live operands; the f32 MFMA holds 2.35 GHz.  Reported BESIDE the nominal-peak fractions, never instead."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_peak_micro.json')))
+    if not files:
+        return {}, None
+    try:
+        cases = json.load(open(files[-1]))['cases']
+    except (OSError, ValueError, KeyError):
+        return {}, None
+    return {c['instruction']: c['tflops'] for c in cases if c['operands'] == 'unit_normal'}, os.path.basename(files[-1])
+
+
 class _StubPipeline:
     """--stub-pipeline: a CPU stand-in with RNRPipeline.render's contract (two frame buffers used alternately) whose frames
     encode their pose, so that the gather check means something.  Control-flow tests only."""
@@ -228,6 +244,19 @@ class _StubPipeline:
         code = pose[:, :3, 3] * 2.0 + proj[:, 0, 0:1] * 1e-3          # [n,3]
         img.copy_(code[:, :, None, None].expand_as(img))
         return img
+
+
+def sustained_block(precision, achieved_tf):
+    """{'sustained_peak': ..., 'frac_of_sustained': ...} for a roofline block (empty if no microbenchmark is committed)."""
+    rates, src = sustained_mfma_tflops()
+    ins, products = {'f32': ('v_mfma_f32_32x32x2_f32', 1), 'bf16x6': ('v_mfma_f32_32x32x16_bf16', 6),
+                     'f16x3': ('v_mfma_f32_32x32x16_f16', 3)}[precision]
+    if ins not in rates:
+        return {}
+    peak = rates[ins] / products
+    return {'sustained_peak': peak, 'frac_of_sustained': achieved_tf / peak,
+            'sustained_peak_source': '%s: %s with random operands sustains %.1f TFLOP/s%s' % (
+                src, ins, rates[ins], '' if products == 1 else ' (/ %d partial products)' % products)}
 
 
 def make_pipeline(sc, args, dev, V, **kw):
@@ -307,6 +336,7 @@ def single_view_block(sc, args, dev):
         'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel (22 launches per view: BatchNorm finalise and shallow split-K '
                                                   'combine inside the conv launches; HIP events bracket the U-Net stage of every call)',
                      'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'stage_ms_per_view': unet_ms,
+                     **sustained_block(args.precision, tf),
                      'alg_flops_per_view': pipe.unet.flops_per_view, 'traffic': traffic,
                      'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)', **tinfo},
         'two_calls_in_flight': {'frames_per_s': 1.0 / dt_fly, 'ms_per_frame': dt_fly * 1e3,
@@ -460,6 +490,7 @@ def main(argv=None):
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
                          **traffic_info,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
+                         **sustained_block(args.precision, achieved_tf),
                          'out_layer_tiles_skipped': skipped,
                          'flops_note': 'executed FLOPs = %.1f GFLOP/view live U-Net minus the out-layer pixel tiles that hold no '
                                        'foreground pixel when --tile-skip is given (never read: the ray renderer zeroes background)'
@@ -576,7 +607,7 @@ def main(argv=None):
                     'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_emu_kernel<%s> (U-Net stage, HIP events)' % prec,
                                  'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent: algorithmic FLOPs of the exact '
                                  'convolution; peak = 2500 dense 16-bit MFMA TFLOP/s / %d partial products)' % products,
-                                 'frac': tf / peak, 'stage_ms_per_step': ums},
+                                 'frac': tf / peak, 'stage_ms_per_step': ums, **sustained_block(prec, tf)},
                     'note': 'RNRPipeline(precision="%s"): %s; full compute on every pixel, one stream; not the headline value'
                             % (prec, what)}
                 if prec == 'f16x3':
