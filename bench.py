@@ -569,6 +569,27 @@ def main(argv=None):
                                                        'ms_per_step': dt2 / args.steps * 1e3,
                                                        'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
                 del pipe2
+        if extras and not fast and world == 1:
+            # the same steps with two of them in flight (RNRPipeline(inflight=2).submit: private activations per slot, the
+            # non-conv stages and kernel tails of one step run under the convolutions of the other); full compute, same frames
+            pf = make_pipeline(sc, args, dev, V, inflight=2)
+
+            def sub(s):
+                lo = (s % (args.steps + args.warmup)) * V
+                sl = slice(lo, lo + V)
+                return pf.submit(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+            for s in range(4):
+                sub(s)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(args.warmup, args.warmup + args.steps):
+                sub(s)
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t1
+            res['with_two_steps_in_flight'] = {'frames_per_s': args.steps * V / dtf, 'ms_per_step': dtf / args.steps * 1e3,
+                                               'note': 'RNRPipeline(inflight=2).submit, %d views per call, everything else as the '
+                                                       'headline; not the headline value' % V}
+            del pf
         emu_last = {}
         if extras and not fast and world == 1 and args.precision == 'f32':
             # fp32 emulated on the 16-bit matrix cores (RNR_CONV_F32_EMU_BF16X6 / _F16X3): opt-in configurations of the same

@@ -154,6 +154,32 @@ struct ShadeParams {
     int H, W;
 };
 
+// sum over the levels of the bilinear fetch of channel quad q at (u, v)  (TextureMapper.forward, network.py:71-85; the
+// integer taps follow misc.py:16-35 exactly: this file is built without FMA contraction)
+__device__ __forceinline__ float4 texture_quad(const ShadeParams& P, float u, float v, int q, int quads) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < P.num_levels; l++) {
+        const int s = P.tex_size[l];
+        const float sm1 = (float)(s - 1);
+        const float x = u * sm1;
+        const float y = sm1 - v * sm1;
+        const Taps t = bilinear_taps(x, y, s, s);
+        const float4* tex = reinterpret_cast<const float4*>(P.tex[l]);
+        const float4 i00 = tex[((size_t)t.y0 * s + t.x0) * quads + q];
+        const float4 i10 = tex[((size_t)t.y1 * s + t.x0) * quads + q];
+        const float4 i01 = tex[((size_t)t.y0 * s + t.x1) * quads + q];
+        const float4 i11 = tex[((size_t)t.y1 * s + t.x1) * quads + q];
+        float4 lv;   // I00*w00 + I10*w10 + I01*w01 + I11*w11 (misc.py:42)
+        lv.x = i00.x * t.w00 + i10.x * t.w10 + i01.x * t.w01 + i11.x * t.w11;
+        lv.y = i00.y * t.w00 + i10.y * t.w10 + i01.y * t.w01 + i11.y * t.w11;
+        lv.z = i00.z * t.w00 + i10.z * t.w10 + i01.z * t.w01 + i11.z * t.w11;
+        lv.w = i00.w * t.w00 + i10.w * t.w10 + i01.w * t.w01 + i11.w * t.w11;
+        if (l == 0) acc = lv;
+        else { acc.x += lv.x; acc.y += lv.y; acc.z += lv.z; acc.w += lv.w; }
+    }
+    return acc;
+}
+
 // geometry record per pixel in LDS: T(3) B(3) N(3) vtan(3) uv(2) alpha(1) sh(9) = 24 floats
 constexpr int GEO = 24;
 
@@ -174,6 +200,27 @@ shade_inputs_kernel(const ShadeParams P) {
         const int p = i / (cp - c_in), c = c_in + i % (cp - c_in);
         tile[p * cp + c] = 0.0f;
     }
+
+    // ---- phase 2a (waves 1..3): the texture gathers, issued FIRST ----
+    // Phase 0 is a chain of dependent loads on 32 lanes of wave 0 (face index -> tangent -> frame); the 16 bilinear gathers
+    // of a (pixel, channel quad) item depend on the uv map only.  With C = 24 the 32 x 6 items are exactly the 192 threads of
+    // waves 1..3, which fetch and blend them while wave 0 walks its chain: the two latency chains of a workgroup overlap
+    // instead of following each other (the kernel is latency-bound).  The SH factor (phase 0's result) is
+    // applied after the barrier; more than 192 items fall back to the loop behind phase 1.
+    const int quads = P.C / 4;
+    const bool tex_early = SH_PIX * quads <= SH_THREADS - 64;
+    float4 tex_acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int tex_p = -1, tex_q = 0;
+#ifndef RNR_ABLATE_SH_NOTEX
+    if (tex_early && tid >= 64 && tid - 64 < SH_PIX * quads) {
+        const int i = tid - 64;
+        tex_p = i / quads; tex_q = i - tex_p * quads;
+        const long pix = pix0 + tex_p;
+        float u = 0.f, v = 0.f;
+        if (pix < P.npix) { u = P.uv_map[pix * 2 + 0]; v = P.uv_map[pix * 2 + 1]; }
+        tex_acc = texture_quad(P, u, v, tex_q, quads);
+    }
+#endif
 
     // ---- phase 0: one lane per pixel: TBN, view direction, SH basis ----
     if (tid < SH_PIX) {
@@ -281,35 +328,9 @@ shade_inputs_kernel(const ShadeParams P) {
     }
 
     // ---- phase 2: (pixel, channel-quad) items: sum over levels of bilinear fetches (network.py:71-85) ----
-    const int quads = P.C / 4;
     const float inv_quads = 1.0f / (float)quads;
-#ifdef RNR_ABLATE_SH_NOTEX
-    if (false)
-#endif
-    for (int i = tid; i < SH_PIX * quads; i += SH_THREADS) {
-        const int p = (int)(((float)i + 0.5f) * inv_quads), q = i - p * quads;
+    auto finish_quad = [&](float4 acc, int p, int q) {
         const float* g = geo + p * GEO;
-        const float u = g[12], v = g[13];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int l = 0; l < P.num_levels; l++) {
-            const int s = P.tex_size[l];
-            const float sm1 = (float)(s - 1);
-            const float x = u * sm1;
-            const float y = sm1 - v * sm1;
-            const Taps t = bilinear_taps(x, y, s, s);
-            const float4* tex = reinterpret_cast<const float4*>(P.tex[l]);
-            const float4 i00 = tex[((size_t)t.y0 * s + t.x0) * quads + q];
-            const float4 i10 = tex[((size_t)t.y1 * s + t.x0) * quads + q];
-            const float4 i01 = tex[((size_t)t.y0 * s + t.x1) * quads + q];
-            const float4 i11 = tex[((size_t)t.y1 * s + t.x1) * quads + q];
-            float4 lv;   // I00*w00 + I10*w10 + I01*w01 + I11*w11 (misc.py:42)
-            lv.x = i00.x * t.w00 + i10.x * t.w10 + i01.x * t.w01 + i11.x * t.w11;
-            lv.y = i00.y * t.w00 + i10.y * t.w10 + i01.y * t.w01 + i11.y * t.w11;
-            lv.z = i00.z * t.w00 + i10.z * t.w10 + i01.z * t.w01 + i11.z * t.w11;
-            lv.w = i00.w * t.w00 + i10.w * t.w10 + i01.w * t.w01 + i11.w * t.w11;
-            if (l == 0) acc = lv;
-            else { acc.x += lv.x; acc.y += lv.y; acc.z += lv.z; acc.w += lv.w; }
-        }
         if (P.sh_start >= 0) {  // output[:, s:s+9] *= sh_basis (network.py:88-89)
             const float* sh = g + 15;
             const int c0 = 4 * q - P.sh_start;
@@ -321,7 +342,18 @@ shade_inputs_kernel(const ShadeParams P) {
         float* tp = tile + p * cp + c_geo + 6 + 4 * q;
         if (((c_geo + 6) & 3) == 0) *reinterpret_cast<float4*>(tp) = acc;     // one ds_write_b128 (rows are 16-byte aligned)
         else { tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w; }
+    };
+#ifndef RNR_ABLATE_SH_NOTEX
+    if (tex_early) {
+        if (tex_p >= 0) finish_quad(tex_acc, tex_p, tex_q);
+    } else {
+        for (int i = tid; i < SH_PIX * quads; i += SH_THREADS) {
+            const int p = (int)(((float)i + 0.5f) * inv_quads), q = i - p * quads;
+            const float* g = geo + p * GEO;
+            finish_quad(texture_quad(P, g[12], g[13], q, quads), p, q);
+        }
     }
+#endif
     __syncthreads();
 
     // ---- phase 3: one coalesced sweep of the tile to HBM ----
