@@ -115,6 +115,7 @@ class RNRPipeline:
             dt, tail = ops.GBUFFER_MAPS[m]
             self._gb[m] = torch.empty((N, S, S) + tail, dtype=dt, device=self.dev)
         self.last = {}
+        self._v_uvz_override = None
         # calls in flight (submit): slot 0 is the pipeline's own state; the others share the packed weights and own the rest
         self.inflight = max(1, int(inflight))
         if self.inflight > 1 and self.n_streams > 1:
@@ -138,13 +139,20 @@ class RNRPipeline:
         lp = torch.as_tensor(lp, dtype=torch.float32)
         self.lp = lp.reshape(lp.shape[-3], lp.shape[-2], 3).contiguous().to(self.dev)
 
-    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False, lighting_idx=0, stage_events=None):
+    def render(self, proj, pose, proj_inv, R_inv, keep_intermediates=False, lighting_idx=0, stage_events=None, v_uvz=None):
         """proj/proj_inv/R_inv [N,3,3], pose [N,4,4] device float32 -> image [N,3,S,S].  The result is a view into one of
         two internal buffers used alternately: it stays valid until the call after next.
         stage_events: optional list; (name, torch.cuda.Event) pairs are appended at the stage boundaries
-        (measurement only — bench.py's per-stage HBM figures)."""
+        (measurement only — bench.py's per-stage HBM figures).
+        v_uvz: optional [N,nv,3] projected NDC vertices (u, v, z_cam) to rasterize INSTEAD of projecting `proj` / `pose`
+        here (parity tests feed the reference's own projection: the integer maps then do not depend on how this device
+        rounds a 3x3 matmul); single-stream calls only."""
         with ops.on_device(self.dev):
-            return self._render(proj, pose, proj_inv, R_inv, keep_intermediates, lighting_idx, stage_events)
+            self._v_uvz_override = v_uvz
+            try:
+                return self._render(proj, pose, proj_inv, R_inv, keep_intermediates, lighting_idx, stage_events)
+            finally:
+                self._v_uvz_override = None
 
     def submit(self, proj, pose, proj_inv, R_inv, lighting_idx=0):
         """One call of the reference's per-view loop (test_rnr.py:265-377), asynchronous: the poses [N <= max_views] are
@@ -194,7 +202,7 @@ class RNRPipeline:
         lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
         image = self._images[self._flip][:N]
         self._flip ^= 1
-        lanes = 1 if (stage_events is not None or keep_intermediates) else min(self.n_streams, N)
+        lanes = 1 if (stage_events is not None or keep_intermediates or self._v_uvz_override is not None) else min(self.n_streams, N)
         if lanes == 1:
             if N > self._lane_unets[0].N:
                 raise RuntimeError('pipeline built with streams=%d: a single-stream call takes at most %d poses'
@@ -227,7 +235,8 @@ class RNRPipeline:
         net_in = self._net_in if slot is None else slot.net_in
         R = pose[lo:hi, :3, :3].contiguous()
         t = pose[lo:hi, :3, 3].contiguous()
-        v_uvz = ops.project_vertices(self.mesh.v, proj[lo:hi], R, t, self.S)
+        ov = getattr(self, '_v_uvz_override', None) if slot is None else None
+        v_uvz = ops.project_vertices(self.mesh.v, proj[lo:hi], R, t, self.S) if ov is None else ov[lo:hi].contiguous()
         gb = {m: gbufs[m][lo:hi] for m in self._gb_maps}
         ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
                               workspace=self._lane_ws[lane] if slot is None else slot.ws)

@@ -32,7 +32,7 @@ for cfg in f32:8 f32:1 f16x3:8 bf16x6:8; do
 done
 # bench.py takes single_view_mode's roofline.traffic from the newest committed views-1 profile: make this run's the newest
 cp $OUT/${TAG}_pmc_per_kernel_f32_steps2_views1.json $ROOT/profiles/
-for v in 1 8; do python scripts/layer_time.py --views $v > $OUT/${TAG}_layer_time_f32_views$v.txt 2>&1; done
+for v in 1 2 4 8; do python scripts/layer_time.py --views $v > $OUT/${TAG}_layer_time_f32_views$v.txt 2>&1; done
 python scripts/emu_layer_table.py > $OUT/${TAG}_emu_layer_table.md 2> $OUT/emu_layer_table.err
 python bench.py --pmc-file $OUT/${TAG}_pmc_per_kernel_f32_steps2_views8.json > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/${TAG}_bench_final.json

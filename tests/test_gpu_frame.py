@@ -188,6 +188,48 @@ def test_frame512_nf64_vs_oracle(precision):
         assert (one - img8[i:i + 1]).abs().max() <= 1e-5, i
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_frame512_nf64_vs_reference_run(golden, precision):
+    """The frame at the benchmarked size against a REFERENCE-RUN fixture (tests/golden/make_golden.py::gen_frame512: the
+    reference's own Rasterizer / TextureMapper / RaySampler / RenderingNet (GCN pass included) / RayRenderer modules on
+    bench.py's scene, spiral view 111): no oracle in between.
+      * integer bar: on the reference's projected vertices (stored) the covered-pixel count and two checksums of the
+        face-index map are EQUAL; with the pipeline's own projection at most 8 pixels differ;
+      * frame: max abs difference <= 3e-5 on the stride-4 grid and on the full-resolution 128 x 128 crop, per-channel sums
+        of the whole frame to 1e-5 relative."""
+    from rnr_amd import scene
+    from rnr_amd.pipeline import RNRPipeline
+    g = golden('frame512_nf64')
+    S, vid = int(g['image_size']), int(g['view'])
+    sc = _bench_scene()
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=int(g['nf0']),
+                       max_views=1, device=DEV, sh_coeff=sc['sh_coeff'], sh_lmax=10, skip_background_tiles=False,
+                       precision=precision)
+    dv = {k: T(v).to(DEV) for k, v in scene.spiral_views(S, [vid]).items()}
+    pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True)
+    own = pipe.last['gb']['face_index_map'].cpu().numpy()
+    # the frame is rendered from the reference's projected vertices: one flipped sliver pixel changes the network input by
+    # O(1) there and, through the U-Net's global receptive field, the whole frame by ~1e-4
+    img = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], v_uvz=T(g['v_ndc']).to(DEV)).cpu()
+    # integer bar on the reference's OWN projected vertices (this host's projection rounds differently in the last bit, which
+    # moves a silhouette sliver pixel or two: DESIGN §4 "CPU-result caveat"): the index map reproduces exactly
+    from rnr_amd import ops
+    gb = ops.rasterize_gbuffer(pipe.mesh, T(g['v_ndc']).to(DEV), None, S, 0.0, 1e5, maps=['face_index_map'])
+    fim = gb['face_index_map'].cpu().numpy()
+    pos = np.arange(fim.size, dtype=np.int64) % 1000003
+    assert int((fim >= 0).sum()) == int(g['covered'])
+    assert int(fim.astype(np.int64)[fim >= 0].sum()) == int(g['index_sum'])
+    assert int((fim.astype(np.int64).reshape(-1) * pos)[fim.reshape(-1) >= 0].sum()) == int(g['index_weighted_sum'])
+    assert int((own != fim).sum()) <= 8                              # the pipeline's own projection: a sliver pixel or two
+    oy, ox = [int(x) for x in g['crop_origin']]
+    d4 = (img[:, :, ::4, ::4] - T(g['image_stride4'])).abs().max()
+    dc = (img[:, :, oy:oy + 128, ox:ox + 128] - T(g['image_crop'])).abs().max()
+    assert float(d4) <= 3e-5 and float(dc) <= 3e-5, (float(d4), float(dc))
+    sums = img.double().sum(dim=(0, 2, 3)).numpy()
+    assert np.allclose(sums, g['image_sum'], rtol=1e-5), (sums, g['image_sum'])
+    assert float(T(g['image_crop']).abs().max()) > 0.1               # the crop shows the object, not background
+
+
 @pytest.mark.parametrize('nf0,precision', [(8, 'f32'), (64, 'f32'), (64, 'f16x3')])
 def test_frame1024_c16_vs_oracle(nf0, precision):
     """BASELINE config 5 on one GPU: 1024x1024, 16-channel neural texture (U-Net input 78 + 6 + 16 = 100 -> 78), lighting

@@ -81,6 +81,20 @@ def test_sphere512_index_map_equals_both_reference_builds(golden):
     assert 0.4 < (r['face_index_map'] >= 0).mean() < 0.7
 
 
+def test_sphere512_worst_fma_view_equals_noncontracted_reference(golden):
+    """The view of the 200-view sweep in which FMA contraction flips the most face indices (tests/fma_sweep_report.json):
+    the HIP index map equals the reference evaluated WITHOUT contraction on all 262 144 pixels, and therefore differs from
+    the contracted builds exactly where those differ from it."""
+    from rnr_amd import scene
+    gf = golden('raster_sphere512_worst_fma')
+    idx = scene.uv_sphere(128, 256)['f_v_idx']
+    faces = gf['v_uvz'][:, idx.astype(np.int64)]
+    r = run_hip_raster(faces, 512, 0.0, 1e5)
+    assert np.array_equal(r['face_index_map'], gf['face_index_map_nofma'])
+    assert int((r['face_index_map'] != gf['face_index_map_fma']).sum()) == int(gf['index_flips']) > 0
+    assert int((r['face_index_map'] != gf['face_index_map_fma_clang']).sum()) == int(gf['index_flips_clang'])
+
+
 @pytest.mark.parametrize('S,nf,seed', [(17, 50, 1), (96, 3000, 2), (256, 20000, 3), (33, 1, 4)])
 def test_random_soup_vs_oracle(S, nf, seed):
     """Ragged sizes, many overlapping faces, slivers and far-away faces, batch of 2."""

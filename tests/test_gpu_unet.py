@@ -430,3 +430,25 @@ def test_plan_built_for_many_views_runs_fewer():
         raw = plan.forward(ops.nchw_to_nhwc(x[:n].to(DEV), plan.in_c_pad))
         y = ops.nhwc_to_nchw(raw, 8, bias=plan.out_bias, apply_tanh=True).cpu()
         assert (y - ref[:n]).abs().max() < 5e-4, n
+
+
+def test_unet_plan_fused_equals_separate_launches(monkeypatch):
+    """UNetPlan on rnr_conv2d_fused (one launch per convolution, the default) vs the same plan on the separate launches of
+    round 2 (RNR_UNET_UNFUSED=1: rnr_conv2d_masked + rnr_bn_finalize_reset per layer): same raw output to 2e-6 (BatchNorm
+    statistics are float64 atomics in both), for 1, 2 and 3 views on a plan built for 3; every sync buffer is zero again
+    afterwards."""
+    from rnr_amd import ops, testing
+    from rnr_amd.unet import UNetPlan
+    sd = testing.unet_state_dict(30, 78, 16, seed=11, out_channels_gcn=16)
+    x = torch.randn(3, 30, 128, 128, generator=torch.Generator().manual_seed(5))
+    fused = UNetPlan(sd, 30, 78, 16, 5, (128, 128), 3, torch.device(DEV))
+    assert fused.fused
+    monkeypatch.setenv('RNR_UNET_UNFUSED', '1')
+    legacy = UNetPlan(sd, 30, 78, 16, 5, (128, 128), 3, torch.device(DEV))
+    assert not legacy.fused
+    for n in (1, 3, 2):
+        a = fused.forward(ops.nchw_to_nhwc(x[:n].to(DEV), fused.in_c_pad)).clone()
+        b = legacy.forward(ops.nchw_to_nhwc(x[:n].to(DEV), legacy.in_c_pad))
+        assert float((a - b)[..., :78].abs().max()) < 2e-6 * max(1.0, float(b[..., :78].abs().max())), n
+    torch.cuda.synchronize()
+    assert all(int(s['sync'].max()) == 0 for s in fused.steps)
