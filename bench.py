@@ -333,8 +333,9 @@ def single_view_block(sc, args, dev):
         'views_per_call': 1, 'views': n1,
         'workload': 'test_rnr.py:265-393: spiral_step720 views in order, one view per call, %dx%d, full HIP RenderingNet' % (args.img_size, args.img_size),
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel (22 launches per view: BatchNorm finalise and shallow split-K '
-                                                  'combine inside the conv launches; HIP events bracket the U-Net stage of every call)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
+                                                  '64^2 -> 32^2 stride-2 layer; everywhere else the BatchNorm finalise and the split-K combine '
+                                                  'happen inside the conv launch; HIP events bracket the U-Net stage of every call)',
                      'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'stage_ms_per_view': unet_ms,
                      **sustained_block(args.precision, tf),
                      'alg_flops_per_view': pipe.unet.flops_per_view, 'traffic': traffic,
