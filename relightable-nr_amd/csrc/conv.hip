@@ -964,418 +964,14 @@ conv_halo_kernel(const ConvParams P) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv_halo_persist_kernel: conv_halo_kernel as a PERSISTENT tile loop (launches without split-K whose tiles outnumber the
-// co-resident workgroups: every big layer at 8 views per launch, the 512^2 layers at one).
-//
-// Workgroup w of G (a multiple of 8, so that it stays on the XCD tile_coords expects) runs tiles w, w + G, w + 2G, ...
-// What a tile boundary costs in conv_halo_kernel — the end of the workgroup, the dispatch of the next one, its slot
-// arithmetic and a first halo fetch with nothing to hide behind (2 us of latency in front of a 30 us tile of the
-// 64-column layers, whose K loop is only 4 - 8 chunks long) — is taken off the critical path:
-//   * the LAST K step of a tile stages the FIRST halo chunk of the next tile into the other LDS buffer and requests its
-//     first weights, exactly as a K step stages its successor inside a tile; the slot arithmetic of the next tile runs in
-//     the issue shadow of that step's MFMAs;
-//   * the epilogue has no barrier: the accumulators go out as buffer stores, and the BatchNorm column sums are added to
-//     fp64 accumulators in LDS (ds_add_f64) that are flushed to the global shards — two atomics per column — only when
-//     the workgroup moves to another view / column tile or ends.  The arrival ticket of the producer-side BatchNorm
-//     then counts the tiles flushed (fetch_add(k)), so n_arrive stays "tiles per view".
-// Operand paths, tiling, XCD order and arithmetic are conv_halo_kernel's; results are bit-identical to it.
-//
-// MEASURED AND NOT ADOPTED (r03): sum of the 22 layers 24.90 ms against 24.56 at 8 views per launch (the 64-column layers
-// +1.7 ... +3.5 %), 3.53 against 3.49 ms at one view.  The K loop itself is spill-free, but (i) gfx950 counts loads and
-// stores on ONE in-order vmcnt, so the weight / halo fetches of the next tile's first taps cannot be waited for before the
-// 64 epilogue stores issued ahead of them have been acknowledged — the write latency the workgroup boundary used to absorb
-// (a fresh workgroup starts with an empty counter) now stalls the wave inside its K loop; (ii) two tiles' scalars exceed the
-// SGPR file (111 spilled to VGPR lanes, 25 VGPRs to scratch around the tile switch).  What would be needed is a second
-// accumulator set to drain tile t during tile t+1 (2 waves per SIMD instead of 3).  Compiled only with
-// -DRNR_EXPERIMENT_PERSIST (scripts/mkvariant.sh persist "-DRNR_EXPERIMENT_PERSIST"); RNR_HALO_PERSIST=0 then disables it at run time.
-// ------------------------------------------------------------------------------------------------
+// (r03 experiment, measured and not adopted: conv_halo_kernel as a persistent tile loop with next-tile prefetch — -1.4 % at 8
+// views per launch, DESIGN.md §3.3.  Kernel and launcher live in conv_persist_experiment.inc and are compiled only with
+// -DRNR_EXPERIMENT_PERSIST.)
 #ifdef RNR_EXPERIMENT_PERSIST
-__device__ __forceinline__ void tile_coords_of(const ConvParams& P, int b, int& mt, int& nt, int& z) {
-    const int total = P.mtiles * P.ntiles * P.zdim;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    nt = id % P.ntiles;
-    const int t = id / P.ntiles;
-    mt = t % P.mtiles;
-    z = t / P.mtiles;
-}
-
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW>
-__global__ void __launch_bounds__(CTHREADS, halo_waves(WM, WN, R16))
-conv_halo_persist_kernel(const ConvParams P) {
-    static_assert(TW == 32 || (TW == 16 && !R16), "tile width");
-    constexpr int RPB = 32 / TW;
-    constexpr int TH = WAVES_M * WM * RPB;
-    constexpr int WCOLS = WN * 32 + R16 * 16;
-    constexpr int BN = WAVES_N * WCOLS;
-    constexpr int NPH = KIND == 1 ? 4 : 1;
-    constexpr int TAPS = KIND == 0 ? 9 : 4;
-    constexpr int HWD = KIND == 1 ? TW + 1 : TW + 2;
-    constexpr int HHT = KIND == 1 ? TH + 1 : TH + 2;
-    constexpr int HP = HWD * HHT;
-    constexpr int ASLOTS = HP * 4;
-    constexpr int APT = (ASLOTS + CTHREADS - 1) / CTHREADS;
-    constexpr int APS = (APT + TAPS - 1) / TAPS;
-    constexpr int HDIST = KIND == 2 ? 1 : RNR_HALO_HDIST;
-    constexpr int ACH = 16 * HP;
-    constexpr int ROWSTEP = RPB * HWD;
-    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                                   // [2][ACH] halo, double-buffered
-    double* red = reinterpret_cast<double*>(smem + 2 * ACH);            // [BN][2] column sums of the tiles since the last flush
-    int* flag = reinterpret_cast<int*>(red + 2 * BN);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int wn0 = wave_n * WCOLS;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int q = tid & 3;
-    const int total = P.mtiles * P.ntiles * P.zdim;
-    const int tiles_x = P.Wo / TW, tiles_y = P.Ho / TH;
-    const int G = gridDim.x;
-
-    struct Tile { int n, y0, x0, par, n0; };
-    auto tile_of = [&](int b) {
-        int mt, nt, z;
-        tile_coords_of(P, b, mt, nt, z);
-        Tile T;
-        T.par = KIND == 2 ? z : 0;
-        T.n0 = nt * BN;
-        T.n = mt / (tiles_x * tiles_y);
-        const int trem = mt - T.n * (tiles_x * tiles_y);
-        T.y0 = (trem / tiles_x) * TH; T.x0 = (trem % tiles_x) * TW;
-        return T;
-    };
-    // first tile at or after b that somebody reads (rnr_conv2d_masked), or >= total
-    auto next_live = [&](int b) {
-        if (P.tile_mask) {
-            while (b < total) {
-                int mt, nt, z;
-                tile_coords_of(P, b, mt, nt, z);
-                if (P.tile_mask[mt]) break;
-                b += G;
-            }
-        }
-        return b;
-    };
-
-    // halo slots of this thread (source pixels of the current tile; rewritten in place for the next tile during the last K step)
-    unsigned spix[KIND == 1 ? 1 : APT];
-    short siy[KIND == 1 ? APT : 1], six[KIND == 1 ? APT : 1];
-    int sdst[APT];
-    float smask[KIND == 2 ? APT : 1];
-#pragma unroll
-    for (int j = 0; j < APT; j++) {
-        int s = tid + CTHREADS * j;
-        if (s >= ASLOTS) s -= ASLOTS;
-        const int hp = s >> 2;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        sdst[j] = ((q >> 1) * HP + hy * HWD + hx) * 4 + 2 * (q & 1);
-    }
-    auto setup_slots = [&](const Tile& T) {
-#pragma unroll
-        for (int j = 0; j < APT; j++) {
-            int s = tid + CTHREADS * j;
-            if (s >= ASLOTS) s -= ASLOTS;
-            const int hp = s >> 2;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            int iy = 0, ix = 0;
-            if (KIND == 0) { iy = reflect1(T.y0 - 1 + hy, P.H); ix = reflect1(T.x0 - 1 + hx, P.W); }
-            else if (KIND == 1) { siy[j] = (short)(2 * (T.y0 + hy)); six[j] = (short)(2 * (T.x0 + hx)); }
-            else {
-                iy = T.y0 - 1 + hy; ix = T.x0 - 1 + hx;
-                const bool inside = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-                smask[j] = inside ? 1.f : 0.f;
-                iy = min(max(iy, 0), P.H - 1); ix = min(max(ix, 0), P.W - 1);
-            }
-            if (KIND != 1) spix[j] = (unsigned)(iy * P.W + ix);
-        }
-    };
-
-    const int nchunks = P.chunks_per_tap;
-    const int steps = nchunks * NPH;                // K steps of a tile: step = chunk * NPH + phase (no split-K here)
-
-    struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; unsigned C; unsigned soff; int act; int phy, phx; float4 sc, sh; };
-    auto chunk_src = [&](const Tile& T, int step) {
-        ChunkSrc cs;
-        const int c = step / NPH;
-        cs.phy = (step % NPH) >> 1; cs.phx = (step % NPH) & 1;
-        const int s = c < P.chunks0 ? 0 : 1;
-        const int cc = (c - (s ? P.chunks0 : 0)) * BK;
-        cs.C = (unsigned)P.src_c[s];
-        cs.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src_data[s] + (size_t)T.n * P.H * P.W * cs.C), 0,
-                                                    0x7fffffff, 0x27000);
-        cs.soff = (unsigned)cc * 4u;
-        cs.act = P.src_act[s];
-        cs.sc = make_float4(1.f, 1.f, 1.f, 1.f);
-        cs.sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.src_scale[s]) cs.sc = *reinterpret_cast<const float4*>(P.src_scale[s] + (size_t)T.n * cs.C + cc + 4 * q);
-        if (P.src_shift[s]) cs.sh = *reinterpret_cast<const float4*>(P.src_shift[s] + (size_t)T.n * cs.C + cc + 4 * q);
-        return cs;
-    };
-    auto load_a = [&](const ChunkSrc& cs, int j) {
-        unsigned pixel;
-        if (KIND == 1) pixel = (unsigned)(reflect1(siy[j] - cs.phy, P.H) * P.W + reflect1(six[j] - cs.phx, P.W));
-        else pixel = spix[j];
-        const unsigned voff = (pixel * cs.C + 4u * (unsigned)q) * 4u;
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, (int)voff, (int)cs.soff, 0));
-    };
-    auto store_a = [&](const ChunkSrc& cs, float4 v, int j, int buf) {
-        float x = apply_act(v.x * cs.sc.x + cs.sh.x, cs.act);
-        float y = apply_act(v.y * cs.sc.y + cs.sh.y, cs.act);
-        float z = apply_act(v.z * cs.sc.z + cs.sh.z, cs.act);
-        float w = apply_act(v.w * cs.sc.w + cs.sh.w, cs.act);
-        if (KIND == 2) { x *= smask[j]; y *= smask[j]; z *= smask[j]; w *= smask[j]; }
-        float* a = As + buf * ACH + sdst[j];
-        *reinterpret_cast<float2*>(a) = make_float2(x, z);
-        *reinterpret_cast<float2*>(a + 2 * HP * 4) = make_float2(y, w);
-    };
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.weight), 0, 0x7fffffff, 0x27000);
-    const unsigned tile_bytes = 64u * (unsigned)P.wstride;
-    unsigned bvoff[2];                               // column tile (n0) is the scalar part of the address
-#pragma unroll
-    for (int sg = 0; sg < 2; sg++)
-        bvoff[sg] = ((unsigned)(2 * h + sg) * (unsigned)P.wstride + (unsigned)(wn0 + l31)) * 16u;
-    const int g16 = (kq & 1) * 2 + (kq >> 1);
-    const unsigned bvoff16 = ((unsigned)g16 * (unsigned)P.wstride + (unsigned)(wn0 + WN * 32 + l15)) * 16u;
-    struct BRegs { floatx4 b[2][WN]; floatx4 b16; };
-    auto load_b = [&](BRegs& dst, const Tile& T, int step, int t) {
-        const int c = step / NPH;
-        int tap = T.par * TAPS + t;
-        if (KIND == 1) {
-            const int phy = (step % NPH) >> 1, phx = (step % NPH) & 1, ta = t >> 1, tb = t & 1;
-            tap = (phy ? 2 * ta : 1 + 2 * ta) * 4 + (phx ? 2 * tb : 1 + 2 * tb);
-        }
-        const unsigned soff = (unsigned)(tap * nchunks + c) * tile_bytes + (unsigned)T.n0 * 16u;      // wave-uniform
-#pragma unroll
-        for (int sg = 0; sg < 2; sg++)
-#pragma unroll
-            for (int j = 0; j < WN; j++)
-                dst.b[sg][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(bvoff[sg] + 512u * j),
-                                                                                             (int)soff, 0));
-        if (R16) dst.b16 = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)bvoff16, (int)soff, 0));
-    };
-
-    // per-lane LDS bases (floats); the parity shift of the transposed conv is a scalar added per tile
-    const float* a_lane = As + ((2 * h) * HP + (wave_m * WM * RPB + l31 / TW) * HWD + l31 % TW) * 4;
-    const float* a16_lane = As + (g16 * HP + wave_m * WM * HWD + l15) * 4;
-
-    int b = next_live(blockIdx.x);
-    if (b >= total) return;                           // workgroup-uniform, before any barrier
-    Tile cur = tile_of(b);
-    setup_slots(cur);
-    if (P.stats) for (int i = tid; i < 2 * BN; i += CTHREADS) red[i] = 0.0;
-    {
-        const ChunkSrc cs = chunk_src(cur, 0);
-#pragma unroll
-        for (int j = 0; j < APT; j++)
-            if (tid + CTHREADS * j < ASLOTS) store_a(cs, load_a(cs, j), j, 0);
-    }
-    BRegs breg[2];
-    load_b(breg[0], cur, 0, 0);
-    __syncthreads();
-    int abuf = 0;
-    int pending = 0;                                  // tiles whose column sums sit in `red`
-
-    floatx16 acc[WM][WN];
-    floatx4 acc16[R16 ? 2 * WM : 1];
-    Tile nxt = cur;
-    bool has_next = false;
-    int bn = b;
-    // One K step.  LAST (compile-time) = the tile's final step: what it stages is the first chunk of the NEXT tile; the
-    // step is peeled out of the loop so that `nxt` is not live across the regular steps (the kernel sits at the register
-    // limit of three waves per SIMD).
-    auto k_step = [&](int c, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        const bool next_chunk = LAST ? has_next : true;
-        const int paroff = KIND == 2 ? (cur.par >> 1) * HWD + (cur.par & 1) : 0;
-        // this tile's halo fetches have all been issued and stored: the slots can turn to the next tile
-        if (LAST && has_next) setup_slots(nxt);
-        const ChunkSrc csn = LAST ? chunk_src(nxt, 0) : chunk_src(cur, c + 1);
-        float4 avr[HDIST < 2 ? 2 : HDIST][APS];
-#pragma unroll
-        for (int t = 0; t < TAPS; t++) {
-            if (t < TAPS - 1) load_b(breg[(t + 1) & 1], cur, c, t + 1);
-            else if (!LAST) load_b(breg[TAPS & 1], cur, c + 1, 0);
-            else if (has_next) load_b(breg[TAPS & 1], nxt, 0, 0);
-            float4 (&av)[APS] = avr[t % (HDIST < 2 ? 2 : HDIST)];
-#pragma unroll
-            for (int u = 0; u < APS; u++) {
-                const int j = t * APS + u;
-                av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (next_chunk && j < APT) av[u] = load_a(csn, j);
-            }
-            int aoff;
-            if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
-            else if (KIND == 1) aoff = (t >> 1) * HWD + (t & 1);
-            else aoff = ((t >> 1) == 0 ? 1 : 0) * HWD + ((t & 1) == 0 ? 1 : 0);
-            const float* a_s = a_lane + (abuf * ACH + paroff * 4) + aoff * 4;
-            const BRegs& bt = breg[t & 1];
-#pragma unroll
-            for (int sg = 0; sg < 2; sg++) {
-                floatx4 a4[WM];
-#pragma unroll
-                for (int i = 0; i < WM; i++) a4[i] = *reinterpret_cast<const floatx4*>(a_s + (sg * HP + i * ROWSTEP) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-#pragma unroll
-                    for (int i = 0; i < WM; i++)
-#pragma unroll
-                        for (int j = 0; j < WN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], bt.b[sg][j][e], acc[i][j], 0, 0, 0);
-            }
-            if (R16) {
-                const floatx4 bv = bt.b16;
-#pragma unroll
-                for (int sb = 0; sb < 2 * WM; sb++) {
-                    const floatx4 av16 = *reinterpret_cast<const floatx4*>(
-                        a16_lane + (abuf * ACH + paroff * 4) + (aoff + (sb >> 1) * ROWSTEP + (sb & 1) * 16) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        acc16[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av16[e], bv[e], acc16[sb], 0, 0, 0);
-                }
-            }
-            const int ts = t - (HDIST - 1);
-            if (ts >= 0) {
-#pragma unroll
-                for (int u = 0; u < APS; u++) {
-                    const int j = ts * APS + u;
-                    if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS)
-                        store_a(csn, avr[ts % (HDIST < 2 ? 2 : HDIST)][u], j, abuf ^ 1);
-                }
-            }
-        }
-#pragma unroll
-        for (int ts = TAPS - (HDIST - 1); ts < TAPS; ts++) {
-            if (ts < 0 || ts * APS >= APT) continue;
-#pragma unroll
-            for (int u = 0; u < APS; u++) {
-                const int j = ts * APS + u;
-                if (next_chunk && j < APT && tid + CTHREADS * j < ASLOTS)
-                    store_a(csn, avr[ts % (HDIST < 2 ? 2 : HDIST)][u], j, abuf ^ 1);
-            }
-        }
-        if (TAPS & 1) breg[0] = breg[1];
-        __syncthreads();                    // this step's halo is free; the next one (of this tile or the next) is complete
-        abuf ^= 1;
-    };
-
-    while (true) {
-#pragma unroll
-        for (int i = 0; i < WM; i++)
-#pragma unroll
-            for (int j = 0; j < WN; j++)
-#pragma unroll
-                for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < (R16 ? 2 * WM : 1); i++) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-        for (int c = 0; c + 1 < steps; c++) k_step(c, std::false_type{});
-        bn = next_live(b + G);
-        has_next = bn < total;
-        if (has_next) nxt = tile_of(bn);
-        k_step(steps - 1, std::true_type{});
-
-        // ---- epilogue of `cur`: no barrier ----
-        store_acc_tiles<KIND, WM, WN, TW>(P, P.out, acc, cur.n, cur.y0, cur.x0, (cur.par >> 1), (cur.par & 1), wave_m, cur.n0, wn0, l31, h);
-        if (R16) {
-            const int col = cur.n0 + wn0 + WN * 32 + l15;
-#pragma unroll
-            for (int sb = 0; sb < 2 * WM; sb++) {
-                const int y = cur.y0 + wave_m * WM + (sb >> 1);
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int x = cur.x0 + (sb & 1) * 16 + kq * 4 + g;
-                    const size_t off = (KIND == 2)
-                        ? (((size_t)cur.n * P.OH + 2 * y + (cur.par >> 1)) * P.OW + 2 * x + (cur.par & 1)) * P.c_out_pad
-                        : (((size_t)cur.n * P.OH + y) * P.OW + x) * P.c_out_pad;
-                    if (col < P.c_out_pad) P.out[off + col] = acc16[sb][g];
-                }
-            }
-        }
-        if (P.stats) {
-#pragma unroll
-            for (int j = 0; j < WN; j++) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < WM; i++)
-#pragma unroll
-                    for (int g = 0; g < 16; g++) {
-                        const float v = acc[i][j][g];
-                        s1 += v;
-                        s2 += v * v;
-                    }
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (h == 0) {
-                    const int col = wn0 + 32 * j + l31;
-                    atomicAdd(&red[2 * col + 0], (double)s1);
-                    atomicAdd(&red[2 * col + 1], (double)s2);
-                }
-            }
-            if (R16) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int sb = 0; sb < 2 * WM; sb++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const float v = acc16[sb][g];
-                        s1 += v;
-                        s2 += v * v;
-                    }
-                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (kq == 0) {
-                    const int col = wn0 + WN * 32 + l15;
-                    atomicAdd(&red[2 * col + 0], (double)s1);
-                    atomicAdd(&red[2 * col + 1], (double)s2);
-                }
-            }
-            pending++;
-            if (!has_next || nxt.n != cur.n || nxt.n0 != cur.n0) {      // workgroup-uniform: leave this (view, column tile)
-                __syncthreads();                                          // every wave's LDS adds have landed
-                if (tid < BN) {
-                    const int col = cur.n0 + tid;
-                    if (col < P.c_out) {
-                        double* st = stat_slot(P, cur.n, col);
-                        atomicAdd(st + 0, red[2 * tid + 0]);
-                        atomicAdd(st + 1, red[2 * tid + 1]);
-                    }
-                    red[2 * tid + 0] = 0.0;
-                    red[2 * tid + 1] = 0.0;
-                }
-                if (P.arrive) {         // producer-side BatchNorm: the ticket counts the tiles behind this flush
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    unsigned* counter = P.arrive + (P.arrive_per_view ? cur.n : 0);
-                    if (tid == 0) {
-                        const unsigned t = __hip_atomic_fetch_add(counter, (unsigned)pending, RNR_RLX_AGENT);
-                        const int last = t + (unsigned)pending == P.n_arrive ? 1 : 0;
-                        *flag = last;
-                        if (last) __hip_atomic_store(counter, 0u, RNR_RLX_AGENT);
-                    }
-                    __syncthreads();
-                    if (*flag) {
-                        if (P.arrive_per_view) bn_finalize_views(P, cur.n, 1, tid);
-                        else bn_finalize_views(P, 0, P.N, tid);
-                    }
-                } else {
-                    __syncthreads();    // the zeroes are in place before the next tile adds
-                }
-                pending = 0;
-            }
-        }
-        if (!has_next) break;
-        cur = nxt;
-        b = bn;
-    }
-}
-#endif  // RNR_EXPERIMENT_PERSIST
+#define RNR_PERSIST_PART 1
+#include "conv_persist_experiment.inc"
+#undef RNR_PERSIST_PART
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // fp32 emulation on the 16-bit matrix cores (opt-in; gfx950's fp32-input MFMA runs at 1/16 of the 16-bit rate).
@@ -1817,30 +1413,9 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
 }
 
 #ifdef RNR_EXPERIMENT_PERSIST
-// conv_halo_persist_kernel for this configuration if the launch has more tiles than co-resident workgroups (and no split-K);
-// false = use conv_halo_kernel.  RNR_HALO_PERSIST=0 in the environment keeps every launch on conv_halo_kernel (A/B).
-template <int KIND, int WAVES_M, int WAVES_N, int WM, int WN, int R16, int TW = 32>
-static bool launch_halo_persist_cfg(long total, const ConvParams& P, hipStream_t st) {
-    static const bool enabled = [] { const char* e = getenv("RNR_HALO_PERSIST"); return !(e && atoi(e) == 0); }();
-    if (!enabled || P.splitk != 1) return false;
-    constexpr int TH = WAVES_M * WM * (32 / TW), BN = WAVES_N * (WN * 32 + R16 * 16);
-    constexpr int HP = (KIND == 1 ? TW + 1 : TW + 2) * (KIND == 1 ? TH + 1 : TH + 2);
-    constexpr size_t lds_min = (size_t)(2 * BK * HP) * sizeof(float) + (size_t)BN * 2 * sizeof(double) + 16;
-    constexpr int nat = halo_waves(WM, WN, R16);
-    constexpr int lds_slots = (int)((160 * 1024) / lds_min);
-    const int slots = balanced_slots(total, nat < lds_slots ? nat : lds_slots);
-    const long G = 256L * slots;                    // a multiple of 8: workgroup w and its tiles w + i G share an XCD
-    if (total <= G) return false;
-    const size_t lds = slots < lds_slots ? (size_t)(160 * 1024 / slots) & ~(size_t)255 : lds_min;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_persist_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16, TW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
-    }
-    hipLaunchKernelGGL((conv_halo_persist_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16, TW>), dim3((unsigned)G), dim3(CTHREADS), lds, st, P);
-    return true;
-}
+#define RNR_PERSIST_PART 2
+#include "conv_persist_experiment.inc"
+#undef RNR_PERSIST_PART
 #endif
 
 // out[m,c] = sum_s slab[s][m,c]; statistics per view.  One float4 of one output row per thread (16 rows x 64 columns
