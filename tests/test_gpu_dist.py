@@ -43,3 +43,24 @@ def test_bench_plain_launch_forced_dist():
     res = _run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--views-per-step', '1', '--no-cpu-baseline',
                 '--main-loop-only', '--check-gather'], env)
     assert res['gather_check']['ok'] is True
+
+
+def test_bench_single_view_block():
+    """The reference's calling mode as a full bench block: `single_view_mode` carries frames/s of the sequential one-view
+    calls, its own roofline (HIP events around the U-Net of every call, nominal and sustained fractions) and the throughput
+    with two calls in flight, whose last frame equals the sequential one."""
+    env = dict(os.environ, RNR_BENCH_FAST='1', RNR_BENCH_SINGLE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RNR_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    res = _run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--views-per-step', '2', '--no-cpu-baseline',
+                '--single-views', '24'], env)
+    sv = res['single_view_mode']
+    assert sv['views_per_call'] == 1 and sv['views'] == 24
+    assert sv['frames_per_s'] > 100.0 and abs(sv['frames_per_s'] * sv['ms_per_frame'] - 1000.0) < 1.0
+    r = sv['roofline']
+    assert r['bound'] == 'mfma' and 0.3 < r['frac'] < 1.0 and r['peak'] == 157.3
+    assert abs(r['achieved'] - r['alg_flops_per_view'] / (r['stage_ms_per_view'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
+    assert r['frac'] < r['frac_of_sustained'] < 1.0
+    fly = sv['two_calls_in_flight']
+    assert fly['frames_per_s'] > 100.0 and fly['max_abs_diff_vs_sequential_last_frame'] < 2e-6
+    assert res['n_ranks_seen'] == 1 and 'stages' in res
