@@ -45,6 +45,9 @@ constexpr int CTHREADS = 256;
 #ifndef RNR_CFG4_MAX
 #define RNR_CFG4_MAX 512             // at most this many 128 x 128 tiles: 128 x 64 tiles instead (make_plan, 3x3 only); 0 = never
 #endif
+#ifndef RNR_CFG0_SMALL_MAX
+#define RNR_CFG0_SMALL_MAX 1024      // at most this many 256 x 64 tiles (one 512^2 view): 128 x 64 tiles, four waves per SIMD, instead
+#endif
 #ifndef RNR_FUSED_BN_MIN_WGS
 #define RNR_FUSED_BN_MIN_WGS 256     // in-kernel BatchNorm finalise for grids larger than this
 #endif
@@ -1746,6 +1749,16 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
             p->ntiles = (d->c_out_pad + p->bn - 1) / p->bn;
         }
     }
+    // ... and the 64-column 3x3 layers (256 x 64 tiles, three waves per SIMD) when one 512^2 view is all there is: 152 -> 148 us
+    // per layer on 128 x 64 tiles; no gain from two views on (RNR_CFG0_SMALL_MAX in the environment overrides)
+    static const int cfg0_small = [] { const char* e = getenv("RNR_CFG0_SMALL_MAX"); return e ? atoi(e) : RNR_CFG0_SMALL_MAX; }();
+    if (p->halo && d->kind == RNR_CONV3x3_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 0 && p->tw == 32 && p->Ho % 4 == 0) {
+        const long t256 = (long)N * (p->Ho / th) * (p->Wo / p->tw) * p->ntiles;
+        if (t256 <= cfg0_small) {
+            p->cfg = 4; p->bm = 128; p->bn = 64; th = 4;
+        }
+    }
+    // (the 80-column out layer was tried on 128 x 80 tiles at one view per call: 364 vs 351 us, not kept)
     // the halo kernels address a view with 32-bit element offsets
     const long view_elems = (long)H * W * (d->c_in0_pad > d->c_in1_pad ? d->c_in0_pad : d->c_in1_pad);
     if (view_elems >= (1L << 30)) p->halo = 0;
