@@ -1752,8 +1752,9 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     // ... and the 64-column 3x3 layers (256 x 64 tiles, three waves per SIMD) when one 512^2 view is all there is: 152 -> 148 us
     // per layer on 128 x 64 tiles; no gain from two views on (RNR_CFG0_SMALL_MAX in the environment overrides)
     static const int cfg0_small = [] { const char* e = getenv("RNR_CFG0_SMALL_MAX"); return e ? atoi(e) : RNR_CFG0_SMALL_MAX; }();
-    if (p->halo && d->kind == RNR_CONV3x3_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 0 && p->tw == 32 && p->Ho % 4 == 0) {
-        const long t256 = (long)N * (p->Ho / th) * (p->Wo / p->tw) * p->ntiles;
+    // (the 64-column transposed conv too: 271 -> 268 us)
+    if (p->halo && d->kind != RNR_CONV4x4S2_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && p->cfg == 0 && p->tw == 32 && p->Ho % 4 == 0) {
+        const long t256 = (long)N * (p->Ho / th) * (p->Wo / p->tw) * p->ntiles * p->par;
         if (t256 <= cfg0_small) {
             p->cfg = 4; p->bm = 128; p->bn = 64; th = 4;
         }
