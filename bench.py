@@ -608,6 +608,19 @@ def main(argv=None):
                                                'note': 'RNRPipeline(inflight=2).submit, %d views per call, everything else as the '
                                                        'headline; not the headline value' % V}
             del pf
+        if extras and not fast and world == 1 and args.precision == 'f32':
+            # the ray renderer folded into the out layer (RNRPipeline(fuse_ray=True): rnr_ray_weights + rnr_conv2d_ray).  Measured
+            # and NOT the default: the weights kernel costs more than ray_render_kernel did
+            try:
+                pr = make_pipeline(sc, args, dev, V, fuse_ray=True)
+                dtr = timed(pr)
+                res['with_ray_renderer_in_out_layer_epilogue'] = {
+                    'frames_per_s': args.steps * V / dtr, 'ms_per_step': dtr / args.steps * 1e3,
+                    'note': 'RNRPipeline(fuse_ray=True): no ray_render_kernel, the out layer writes 12 B/px instead of 320; '
+                            'everything else as the headline; slower than the separate kernel, not the headline value'}
+                del pr
+            except Exception as e:          # noqa: BLE001 - an extra must never fail the bench line
+                res['with_ray_renderer_in_out_layer_epilogue'] = {'error': str(e)[:200]}
         emu_last = {}
         if extras and not fast and world == 1 and args.precision == 'f32':
             # fp32 emulated on the 16-bit matrix cores (RNR_CONV_F32_EMU_BF16X6 / _F16X3): opt-in configurations of the same

@@ -331,6 +331,28 @@ int rnr_conv2d_fused(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr
                      void* workspace, size_t workspace_bytes, void* sync, size_t sync_bytes, const uint8_t* tile_mask,
                      void* stream);
 
+/*
+ * The ray renderer folded into the out layer (opt-in: RNRPipeline(fuse_ray=True); network.py:253, 481-527, test_rnr.py:357-368).
+ *   rnr_ray_weights  the half that does not depend on the U-Net: for pixel p, ray r, colour channel c
+ *                        ray_w[p, 3 r + c] = albedo_group(r)[p, c] * env-map colour(direction of ray r)[c] / rays in the group
+ *                    from the ray directions / albedo channels of net_in and the light probe (same arithmetic as
+ *                    rnr_ray_render); background pixels (alpha = 0) and the padding columns >= 3 * rays get 0.
+ *                    ray_w [N, H, W, c_w], c_w = the out layer's c_out_pad.
+ *   rnr_conv2d_ray   the out-layer convolution whose epilogue produces the FRAME instead of its 78-channel output:
+ *                        image[n, c, y, x] = sum_r (tanh(conv[n, y, x, 3 r + c] + bias[3 r + c]) + 1) * ray_w[n, y, x, 3 r + c]
+ *                    straight from the MFMA accumulators (LDS transpose, 26 columns per sum): 12 bytes per pixel leave the
+ *                    kernel instead of 320.  Only the exact-fp32 3x3 convolution on the 80-column plan (65 <= c_out <= 80,
+ *                    c_out = 3 x rays, map width a multiple of 32, height of 8); anything else returns an error — run
+ *                    rnr_conv2d_masked + rnr_ray_render there.  tile_mask as in rnr_conv2d_masked (skipped tiles get 0).
+ * Differs from rnr_ray_render in summation order only (<= 1e-6 on frames in [0, 2]).
+ */
+int rnr_ray_weights(const float* net_in, int c_pad, const float* alpha, const float* lp, int lp_h, int lp_w, int num_spec,
+                    int num_diff, int albedo_diff_ch, int albedo_spec_ch, float* ray_w, int c_w, int num_views, int height,
+                    int width, void* stream);
+int rnr_conv2d_ray(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1, const float* weight_packed,
+                   const float* ray_w, const float* bias, float* image, int num_views, int in_h, int in_w,
+                   const uint8_t* tile_mask, void* stream);
+
 /* stats [N,c_pad,2] (sum, sumsq over `count` pixels) + gamma/beta [channels] -> scale/shift [N,c_pad]:
  * scale = gamma / sqrt(var_biased + eps), shift = beta - mean * scale  (BatchNorm2d in train mode: per-view
  * batch statistics, biased variance); channels >= `channels` get scale = shift = 0. */

@@ -97,6 +97,10 @@ struct ConvParams {
     const float* gamma; const float* beta; float* scale; float* shift;
     float eps; double count;    // pixels per view behind one statistic
     unsigned* tile_arrive;      // [par * mtiles * ntiles] split-K slices of a tile that have published their slab; NULL = legacy slabs + reduce kernel
+    // ---- rnr_conv2d_ray: the U-Net-dependent half of the ray renderer in the out layer's epilogue (80-column configuration) ----
+    const float* ray_w;         // [N*OH*OW][c_out_pad] ray weights (rnr_ray_weights); NULL = ordinary epilogue
+    const float* ray_bias;      // [c_out_pad] out-layer bias
+    float* ray_image;           // [N,3,OH,OW]
     int par_inner;              // tile order of the transposed conv: parity class inside the pixel tile (see tile_coords)
     float* slabs;               // in-launch combine: [splitk][tile][wave][i][j][4 quads][64 lanes][4] accumulator images
 };
@@ -656,7 +660,6 @@ conv_halo_kernel(const ConvParams P) {
     const int l15 = lane & 15, kq = lane >> 4;
     int mt_, nt_, z_;
     tile_coords(P, mt_, nt_, z_);
-    if (P.tile_mask && P.tile_mask[mt_] == 0) return;       // workgroup-uniform, before any barrier
     const int par = (KIND == 2) ? (z_ & 3) : 0;
     const int split = (KIND == 2) ? (z_ >> 2) : z_;
     const int py = par >> 1, px = par & 1;
@@ -666,6 +669,16 @@ conv_halo_kernel(const ConvParams P) {
     const int n = mt_ / (tiles_x * tiles_y);
     const int trem = mt_ - n * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    if (P.tile_mask && P.tile_mask[mt_] == 0) {             // workgroup-uniform, before any barrier
+        if (R16 && KIND == 0 && P.ray_w) {                  // nobody computes this tile: its pixels are background, the frame is 0 there
+            const int hw = P.OH * P.OW;
+            for (int it = tid; it < 3 * TH * TW; it += CTHREADS) {
+                const int c = it / (TH * TW), pl = it - c * (TH * TW);
+                P.ray_image[((size_t)n * 3 + c) * hw + (size_t)(y0 + pl / TW) * P.OW + x0 + pl % TW] = 0.0f;
+            }
+        }
+        return;
+    }
 
     // halo slots of this thread: fixed source pixels for the whole K loop.  Slots past the halo fetch a valid address
     // (an earlier slot's) and are never stored; the zero border of the transposed conv is a 0/1 factor.
@@ -877,6 +890,57 @@ conv_halo_kernel(const ConvParams P) {
 #endif
         if (TAPS & 1) breg[0] = breg[1];
         __syncthreads();                    // everybody is done reading this step's halo; the next one is complete
+    }
+
+    // ---- epilogue of rnr_conv2d_ray: frame = sum over the 26 rays of (tanh(y + b) + 1) * W, straight from the accumulators ----
+    // Two passes (one image row per wave each): every lane scales the elements it holds — lanes of a wave are consecutive
+    // columns, so the weights arrive as coalesced 128-byte rows — and parks them in LDS as [pixel][column]; after a barrier
+    // 128 pixels x 3 colour channels are summed over their 26 columns (stride 3) and written as three coalesced row pieces.
+    if (R16 && KIND == 0 && P.ray_w) {
+        static_assert(!R16 || TW == 32, "remainder configuration");
+        float* tbuf = As;                                   // [WAVES_M * 32 pixels][c_out_pad]: 40 KB of the 43 KB halo buffers
+        const int cw = P.c_out_pad, hw = P.OH * P.OW;
+        float bj[WN];
+#pragma unroll
+        for (int j = 0; j < WN; j++) bj[j] = P.ray_bias[n0 + wn0 + 32 * j + l31];
+        const float b16 = P.ray_bias[n0 + wn0 + WN * 32 + l15];
+#pragma unroll
+        for (int i = 0; i < WM; i++) {
+            const int y = y0 + wave_m * WM + i;
+            const float* wrow = P.ray_w + (((size_t)n * P.OH + y) * P.OW + x0) * cw;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const int xx = (g & 3) + 8 * (g >> 2) + 4 * h;
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int col = wn0 + 32 * j + l31;
+                    const float w = wrow[xx * cw + col];
+                    const float v = fast_tanh_plus1f(acc[i][j][g] + bj[j]) * w;
+                    tbuf[(wave_m * 32 + xx) * cw + col] = (w == 0.0f) ? 0.0f : v;       // background (and padding) columns: exactly 0
+                }
+            }
+#pragma unroll
+            for (int half16 = 0; half16 < 2; half16++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int xx = half16 * 16 + kq * 4 + g4, col = wn0 + WN * 32 + l15;
+                    const float w = wrow[xx * cw + col];
+                    const float v = fast_tanh_plus1f(acc16[2 * i + half16][g4] + b16) * w;
+                    tbuf[(wave_m * 32 + xx) * cw + col] = (w == 0.0f) ? 0.0f : v;
+                }
+            __syncthreads();
+            const int n_cols = P.c_out / 3;                 // rays
+            for (int it = tid; it < 3 * WAVES_M * 32; it += CTHREADS) {
+                const int c = it / (WAVES_M * 32), pl = it - c * (WAVES_M * 32);
+                const float* tp = tbuf + pl * cw + c;
+                float sum = 0.0f;
+                for (int r = 0; r < n_cols; r++) sum += tp[3 * r];
+                const int yy = y0 + (pl >> 5) * WM + i;
+                P.ray_image[((size_t)n * 3 + c) * hw + (size_t)yy * P.OW + x0 + (pl & 31)] = sum;
+            }
+            __syncthreads();                                // the next pass overwrites tbuf
+        }
+        return;
     }
 
     // ---- epilogue ----
@@ -1952,6 +2016,9 @@ extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha,
     return check_launch("active_tile_kernel");
 }
 
+struct RayEpilogue { const float* w; const float* bias; float* image; };
+static thread_local RayEpilogue g_ray = {nullptr, nullptr, nullptr};      // set by rnr_conv2d_ray around conv2d_run
+
 static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1, const float* weight_packed,
                       float* out_raw, double* stats, const rnr_conv_bn* bn, void* sync, size_t sync_bytes, int num_views,
                       int in_h, int in_w, void* workspace, size_t workspace_bytes, const uint8_t* tile_mask, void* stream) {
@@ -1972,6 +2039,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     hipStream_t st = as_stream(stream);
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
+    if (g_ray.w) pl.splitk = 1;         // the ray-renderer epilogue needs the whole K sum in one workgroup (small maps would split)
     ConvParams P = {};
     P.src_data[0] = src0->data; P.src_scale[0] = src0->scale; P.src_shift[0] = src0->shift;
     P.src_c[0] = src0->channels; P.src_act[0] = src0->act;
@@ -1985,6 +2053,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     P.chunks0 = d->c_in0_pad / BK; P.chunks_per_tap = pl.chunks_per_tap; P.kt_total = pl.kt_total;
     P.splitk = pl.splitk;
     P.mtiles = pl.mtiles; P.ntiles = pl.ntiles; P.zdim = pl.splitk * pl.par;
+    P.ray_w = g_ray.w; P.ray_bias = g_ray.bias; P.ray_image = g_ray.image;
     if (d->kind == RNR_CONVT4x4S2) {
         // Each parity class is its own workgroup and stages the same input halo.  With the class as the slowest tile index the
         // input is streamed from HBM four times (r02 PMC: 2.9x the compulsory bytes on the 64-column transposed conv); as
@@ -2097,6 +2166,24 @@ extern "C" int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src
                                  void* stream) {
     return conv2d_run(d, src0, src1, weight_packed, out_raw, stats, nullptr, nullptr, 0, num_views, in_h, in_w, workspace,
                       workspace_bytes, tile_mask, stream);
+}
+
+extern "C" int rnr_conv2d_ray(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,
+                              const float* weight_packed, const float* ray_w, const float* bias, float* image, int num_views,
+                              int in_h, int in_w, const uint8_t* tile_mask, void* stream) {
+    RNR_REQUIRE(ray_w && bias && image, "rnr_conv2d_ray: null pointer argument");
+    if (int e = check_desc(d, "rnr_conv2d_ray")) return e;
+    ConvPlan pl;
+    make_plan(d, num_views, in_h, in_w, &pl);
+    RNR_REQUIRE(d->kind == RNR_CONV3x3_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && pl.cfg == 1 && pl.tw == 32 &&
+                    d->c_out % 3 == 0 && d->c_out_pad == 80,
+                "rnr_conv2d_ray: only the exact-fp32 3x3 out layer on the 80-column plan (65 <= c_out <= 80, c_out = 3 x rays, map "
+                "width a multiple of 32, height of 8) has the ray-renderer epilogue; run rnr_conv2d_masked + rnr_ray_render otherwise");
+    g_ray = {ray_w, bias, image};
+    const int rc = conv2d_run(d, src0, src1, weight_packed, image /* never written as out_raw */, nullptr, nullptr, nullptr, 0,
+                              num_views, in_h, in_w, nullptr, 0, tile_mask, stream);
+    g_ray = {nullptr, nullptr, nullptr};
+    return rc;
 }
 
 extern "C" int rnr_conv2d_fused(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,

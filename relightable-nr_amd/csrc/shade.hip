@@ -420,13 +420,6 @@ __device__ __forceinline__ float fast_acosf(float x) {
     return x < 0.0f ? 3.14159265358979324f - r : r;
 }
 
-// tanh(x) + 1 = 2 - 2 / (e^{2x} + 1) on v_exp_f32 / v_rcp_f32 (the light transport factor of the ray renderer): absolute
-// error ~1e-7, exact limits at +-inf; ocml's tanhf costs ~25 instructions and this kernel is VALU-bound.
-__device__ __forceinline__ float fast_tanh_plus1f(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 2.0f);
-}
-
 struct RayParams {
     const float* unet_raw; int c_out_pad;
     const float* bias;
@@ -590,6 +583,92 @@ ray_render_kernel(const RayParams P) {
                 P.image[(n * 3 + c) * P.hw + rem] = out;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray weights: the part of the ray renderer that does not depend on the U-Net (rnr_ray_weights; the rest runs in the
+// out-layer convolution's epilogue, rnr_conv2d_ray).  For pixel p, ray r, colour channel c
+//     W[p][3 r + c] = albedo_group(r)[p][c] * env-map colour(direction of ray r)[c] / rays in the group
+// so that the frame is  image[p][c] = sum_r (tanh(y[p][3 r + c] + b[3 r + c]) + 1) * W[p][3 r + c]  (network.py:253, 481-527,
+// test_rnr.py:357-359).  Same lane layout, uv arithmetic and taps as ray_render_kernel; background pixels get W = 0.
+// ------------------------------------------------------------------------------------------------
+struct RayWeightParams {
+    const float* net_in; int c_pad;
+    const float* alpha;
+    const float* lp; int lp_h, lp_w;
+    int n_spec, n_diff, alb_diff_ch, alb_spec_ch;
+    float* ray_w; int c_w;          // [npix][c_w], c_w >= 3 * rays (padding columns are written as zeros)
+    long npix;
+    int ni_need;
+};
+
+__global__ void __launch_bounds__(256)
+ray_weights_kernel(const RayWeightParams P) {
+    constexpr int PIX_PER_WG = 8 * RR_PIX;
+    const long wg_pix0 = (long)blockIdx.x * PIX_PER_WG;
+    const int sub = (int)(threadIdx.x & 31);
+    const int lp0 = (int)(threadIdx.x >> 5) * RR_PIX;
+    const bool is_diff = sub >= 16;
+    const int rr = sub & 15;
+    const bool ray_live = is_diff ? rr < P.n_diff : rr < P.n_spec;
+    const int r = is_diff ? P.n_spec + rr : rr;
+    const float* wg_net_in = P.net_in + wg_pix0 * P.c_pad;
+    const float* wg_alpha = P.alpha + wg_pix0;
+    extern __shared__ __attribute__((aligned(16))) float rw_smem[];
+    const int ni_need = P.ni_need;
+    float* s_ni = rw_smem;                                  // [PIX_PER_WG][ni_need]
+    float* s_w = rw_smem + PIX_PER_WG * ni_need;            // [PIX_PER_WG][c_w]: the weights leave as coalesced float4 rows
+    const int wg_valid = (int)min((long)PIX_PER_WG, P.npix - wg_pix0);
+    {
+        const int q_ni = ni_need >> 2;
+        const float inv_q = 1.0f / (float)q_ni;
+        for (int i = threadIdx.x; i < wg_valid * q_ni; i += 256) {
+            const int p = (int)(((float)i + 0.5f) * inv_q), q4 = i - __mul24(p, q_ni);
+            reinterpret_cast<float4*>(s_ni)[i] = *reinterpret_cast<const float4*>(wg_net_in + (unsigned)(__mul24(p, P.c_pad) + 4 * q4));
+        }
+    }
+    float al[RR_PIX];
+#pragma unroll
+    for (int k = 0; k < RR_PIX; k++) al[k] = (lp0 + k < wg_valid) ? wg_alpha[lp0 + k] : 0.0f;
+    __syncthreads();
+    const int lp_w3 = P.lp_w * 3;
+    const float inv_n = is_diff ? (P.n_diff > 0 ? 1.0f / (float)P.n_diff : 0.0f) : 1.0f / (float)P.n_spec;
+    const int alb_ch = 3 * (P.n_spec + P.n_diff) + 6 + (is_diff ? P.alb_diff_ch : P.alb_spec_ch);
+    const int n_cols = 3 * (P.n_spec + P.n_diff);
+#pragma unroll
+    for (int k = 0; k < RR_PIX; k++) {
+        if (lp0 + k >= wg_valid) continue;
+        float* out = s_w + __mul24(lp0 + k, P.c_w);
+        if (sub == 31) for (int c = n_cols; c < P.c_w; c++) out[c] = 0.0f;        // padding columns (lane 31 never holds a ray)
+        if (!ray_live) continue;
+        const float* d = s_ni + __mul24(lp0 + k, ni_need) + 3 * r;
+        float u = __builtin_fmaf(fast_atan2f(d[2], d[0]), 0.5f / RNR_PI_F, 0.5f);      // render.py:96-102; network.py:469-470
+        float v = fast_acosf(d[1]) * (1.0f / RNR_PI_F);
+        const float bg = (al[k] == 0.0f) ? 1.0f : 0.0f;
+        u = u * al[k] - bg;
+        v = v * al[k] - bg;
+        const float x = fminf(u * (float)P.lp_w, (float)(P.lp_w - 1));                  // network.py:497; misc.py:5-42
+        const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
+        const Taps t = bilinear_taps(x, y, P.lp_w, P.lp_h);
+        const unsigned r0 = __umul24((unsigned)t.y0, (unsigned)lp_w3), r1 = __umul24((unsigned)t.y1, (unsigned)lp_w3);
+        const unsigned q0 = __umul24((unsigned)t.x0, 3u), q1 = __umul24((unsigned)t.x1, 3u);
+        const float* l00 = P.lp + (r0 + q0);
+        const float* l10 = P.lp + (r1 + q0);
+        const float* l01 = P.lp + (r0 + q1);
+        const float* l11 = P.lp + (r1 + q1);
+        const float* alb = s_ni + __mul24(lp0 + k, ni_need) + alb_ch;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float col = __builtin_fmaf(l11[c], t.w11, __builtin_fmaf(l01[c], t.w01, __builtin_fmaf(l10[c], t.w10, l00[c] * t.w00)));
+            out[3 * r + c] = (al[k] == 0.0f) ? 0.0f : alb[c] * (col * inv_n);
+        }
+    }
+    __syncthreads();
+    {
+        const int n4 = wg_valid * P.c_w / 4;               // c_w is a multiple of 4 (the out layer's channel stride)
+        float4* dst = reinterpret_cast<float4*>(P.ray_w + wg_pix0 * P.c_w);
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = reinterpret_cast<const float4*>(s_w)[i];
     }
 }
 
@@ -980,6 +1059,28 @@ extern "C" int rnr_ray_render(const float* unet_raw, int c_out_pad, const float*
     RNR_REQUIRE(lds <= 64 * 1024, "rnr_ray_render: rows too wide for the LDS staging (%zu bytes)", lds);
     hipLaunchKernelGGL(ray_render_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), lds, as_stream(stream), P);
     return check_launch("ray_render_kernel");
+}
+
+extern "C" int rnr_ray_weights(const float* net_in, int c_pad, const float* alpha, const float* lp, int lp_h, int lp_w,
+                               int num_spec, int num_diff, int albedo_diff_ch, int albedo_spec_ch, float* ray_w, int c_w,
+                               int num_views, int height, int width, void* stream) {
+    RNR_REQUIRE(net_in && alpha && lp && ray_w, "rnr_ray_weights: null pointer argument");
+    RNR_REQUIRE(num_spec >= 1 && num_spec <= 16 && num_diff >= 0 && num_diff <= 15,
+                "rnr_ray_weights: at most 16 specular / 15 diffuse rays (got %d, %d)", num_spec, num_diff);
+    RNR_REQUIRE(lp_h >= 2 && lp_w >= 2, "rnr_ray_weights: bad light-probe size");
+    RNR_REQUIRE(c_w >= 3 * (num_spec + num_diff), "rnr_ray_weights: c_w %d < 3 * rays", c_w);
+    RayWeightParams P;
+    P.net_in = net_in; P.c_pad = c_pad; P.alpha = alpha; P.lp = lp; P.lp_h = lp_h; P.lp_w = lp_w;
+    P.n_spec = num_spec; P.n_diff = num_diff; P.alb_diff_ch = albedo_diff_ch; P.alb_spec_ch = albedo_spec_ch;
+    P.ray_w = ray_w; P.c_w = c_w; P.npix = (long)num_views * height * width;
+    const int alb_hi = (albedo_diff_ch > albedo_spec_ch ? albedo_diff_ch : albedo_spec_ch) + 3;
+    P.ni_need = (3 * (num_spec + num_diff) + 6 + alb_hi + 3) / 4 * 4;
+    RNR_REQUIRE(P.ni_need <= c_pad && c_pad % 4 == 0, "rnr_ray_weights: channel stride must be a multiple of 4 and cover the albedo channels");
+    const long lanes = (P.npix + RR_PIX - 1) / RR_PIX * 32;
+    RNR_REQUIRE(c_w % 4 == 0, "rnr_ray_weights: c_w must be a multiple of 4");
+    const size_t lds = (size_t)(8 * RR_PIX) * (size_t)(P.ni_need + c_w) * sizeof(float);
+    hipLaunchKernelGGL(ray_weights_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), lds, as_stream(stream), P);
+    return check_launch("ray_weights_kernel");
 }
 
 extern "C" int rnr_sh_basis(const float* dirs, float* out, int n, int lmax, void* stream) {

@@ -89,6 +89,10 @@ SIGNATURES = {
     'rnr_conv_sync_bytes': (c_size_t, [P(RnrConvDesc), c_int, c_int, c_int]),
     'rnr_conv2d_fused': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, P(RnrConvBn), c_int, c_int,
                                  c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'rnr_ray_weights': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                c_int, c_int, c_int, c_void_p]),
+    'rnr_conv2d_ray': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                               c_int, c_void_p, c_void_p]),
     'rnr_bn_finalize': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_bn_finalize_reset': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_float, c_void_p]),
     'rnr_bn_finalize_batch': (c_int, [c_void_p] * 7 + [c_float, c_int, c_int, c_int, c_double, c_float, c_void_p]),

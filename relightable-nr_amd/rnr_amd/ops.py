@@ -340,6 +340,21 @@ def ray_render(unet_raw, bias, net_in, alpha, lp, num_spec, num_diff, albedo_dif
 
 
 @_device_op
+def ray_weights(net_in, alpha, lp, num_spec, num_diff, c_w, albedo_diff_ch=0, albedo_spec_ch=3, out=None):
+    """The U-Net-independent half of the ray renderer (rnr_ray_weights): [N,H,W,c_w] weights W with
+    frame[c] = sum_r (tanh(y[3r+c] + b) + 1) * W[3r+c]; consumed by UNetPlan.forward(..., ray=...) (rnr_conv2d_ray)."""
+    L = _lib.load()
+    N, H, W, cp = net_in.shape
+    if out is None:
+        out = torch.empty(N, H, W, int(c_w), dtype=torch.float32, device=net_in.device)
+    lp3 = lp.reshape(lp.shape[-3], lp.shape[-2], 3)
+    check(L.rnr_ray_weights(_ptr(_chk(net_in, 'net_in')), cp, _ptr(_chk(alpha, 'alpha')), _ptr(_chk(lp3, 'lp')), lp3.shape[0],
+                            lp3.shape[1], int(num_spec), int(num_diff), int(albedo_diff_ch), int(albedo_spec_ch), _ptr(out),
+                            int(c_w), N, H, W, _stream()))
+    return out
+
+
+@_device_op
 def sh_basis(dirs, lmax):
     """sph_harm.evaluate_sh_basis: dirs [n,3] -> [n,(lmax+1)^2] float32."""
     L = _lib.load()

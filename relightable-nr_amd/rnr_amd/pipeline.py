@@ -47,7 +47,7 @@ class _Slot:
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
                  sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10,
-                 skip_background_tiles=True, streams=1, precision='f32', inflight=1):
+                 skip_background_tiles=True, streams=1, precision='f32', inflight=1, fuse_ray=False):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
@@ -59,6 +59,10 @@ class RNRPipeline:
             (like `lighting_model(lighting_idx, is_lp=True)` inside RayRenderer.forward, network.py:494-495)
         """
         self.dev = torch.device(device)
+        # fuse_ray: the ray renderer split in two — ops.ray_weights (everything that does not depend on the U-Net) and the out
+        # layer's epilogue (rnr_conv2d_ray: bias + tanh + the sum over the 26 rays, straight from the accumulators) — instead
+        # of ray_render_kernel behind a 320 B/px round trip of the out layer's output.  Exact fp32, 80-column out layer only.
+        self.fuse_ray = bool(fuse_ray)
         # the ray renderer outputs exactly 0 on background pixels whatever the U-Net produced there (network.py:469-470,
         # 497): the out layer need not compute pixel tiles that contain no foreground pixel.  Frames are bit-identical.
         self.skip_background_tiles = bool(skip_background_tiles)
@@ -134,6 +138,16 @@ class RNRPipeline:
             sl.images = [torch.empty(N, 3, S, S, dtype=torch.float32, device=self.dev) for _ in range(2)]
             sl.flip = 0
             self._slots.append(sl)
+
+    def _ray_w(self, slot, lane):
+        """[max_views,S,S,c_out_pad] ray-weight buffer of the pipeline (shared by the view-group lanes, which use disjoint
+        view ranges) or of a slot."""
+        owner = self if slot is None else slot
+        buf = getattr(owner, '_ray_w_buf', None)
+        if buf is None:
+            buf = torch.empty(self.max_views, self.S, self.S, self.unet.out.c_pad, dtype=torch.float32, device=self.dev)
+            owner._ray_w_buf = buf
+        return buf
 
     def set_light_probe(self, lp):
         lp = torch.as_tensor(lp, dtype=torch.float32)
@@ -244,9 +258,17 @@ class RNRPipeline:
         sh = ops.shade_inputs(gb, self.mesh, proj_inv[lo:hi], R_inv[lo:hi], self.textures, self.pivots_spec,
                               self.pivots_diff, self.sh_start_ch, c_pad=unet.in_c_pad, net_in=net_in[lo:hi])
         mark('shade_inputs')
-        raw = unet.forward(sh['net_in'], n, gb['alpha'] if self.skip_background_tiles else None)
-        mark('unet')
-        ops.ray_render(raw, unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff, albedo_diff_ch=0,
-                       albedo_spec_ch=3, image=image[lo:hi])
-        mark('ray_render')
+        if self.fuse_ray:
+            ray_w = ops.ray_weights(sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff, unet.out.c_pad, albedo_diff_ch=0,
+                                    albedo_spec_ch=3, out=self._ray_w(slot, lane)[lo:hi] if slot is None else self._ray_w(slot, lane)[:n])
+            mark('ray_weights')
+            unet.forward(sh['net_in'], n, gb['alpha'] if self.skip_background_tiles else None, ray=(ray_w, image[lo:hi]))
+            mark('unet')
+            raw = None
+        else:
+            raw = unet.forward(sh['net_in'], n, gb['alpha'] if self.skip_background_tiles else None)
+            mark('unet')
+            ops.ray_render(raw, unet.out_bias, sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff, albedo_diff_ch=0,
+                           albedo_spec_ch=3, image=image[lo:hi])
+            mark('ray_render')
         return {'v_uvz': v_uvz, 'gb': gb, 'net_in': sh['net_in'], 'unet_raw': raw}

@@ -184,14 +184,17 @@ class UNetPlan:
         return RnrConvSrc(a.data.data_ptr(), a.scale.data_ptr() if a.scale is not None else None,
                           a.shift.data_ptr() if a.shift is not None else None, a.c_pad, a.act)
 
-    def forward(self, net_in, n_views=None, consumer_alpha=None):
+    def forward(self, net_in, n_views=None, consumer_alpha=None, ray=None):
         """net_in [n,H,W,in_c_pad] channel-last -> raw out-layer output [n,H,W,out_c_pad] (bias/tanh NOT applied).
         consumer_alpha [n,H,W]: promise that the caller reads the result only where alpha > 0 (the ray renderer zeroes
-        background pixels); the out layer then skips pixel tiles without any such pixel and leaves them unwritten."""
+        background pixels); the out layer then skips pixel tiles without any such pixel and leaves them unwritten.
+        ray = (ray_w [n,H,W,out_c_pad], image [n,3,H,W]): the out layer's epilogue applies bias + tanh and the ray weights
+        (ops.ray_weights) and writes the FRAME into `image` (rnr_conv2d_ray); the raw output is then not produced and the
+        call returns `image`.  Raises if the out layer is not on the plan that has this epilogue (`supports_ray`)."""
         with on_device(self.dev):
-            return self._forward(net_in, n_views, consumer_alpha)
+            return self._forward(net_in, n_views, consumer_alpha, ray)
 
-    def _forward(self, net_in, n_views, consumer_alpha):
+    def _forward(self, net_in, n_views, consumer_alpha, ray=None):
         n = net_in.shape[0] if n_views is None else n_views
         if net_in.device != torch.device(self.dev) and not (net_in.is_cuda and torch.device(self.dev).index is None):
             raise RuntimeError('net_in lives on %s, the plan on %s' % (net_in.device, self.dev))
@@ -213,7 +216,7 @@ class UNetPlan:
                 mask = self._tile_mask
                 check(L.rnr_conv_active_tiles(ctypes.byref(last['desc']), _ptr(consumer_alpha), _ptr(mask), n, h, w, st))
         try:
-            self._run_steps(n, mask, L, st)
+            self._run_steps(n, mask, L, st, ray)
         except Exception:
             for s in self.steps:            # a failed launch may leave statistics half-accumulated: restore the invariant
                 if s['bn'] and s['bn']['stats'] is not None:
@@ -221,9 +224,9 @@ class UNetPlan:
                 if s['sync'] is not None:
                     s['sync'].zero_()
             raise
-        return self.out.data[:n]
+        return self.out.data[:n] if ray is None else ray[1]
 
-    def _run_steps(self, n, mask, L, st):
+    def _run_steps(self, n, mask, L, st, ray=None):
         last = self.steps[-1]
         for s in self.steps:
             srcs = s['srcs']
@@ -231,6 +234,12 @@ class UNetPlan:
             s1 = self._src(srcs[1], n) if len(srcs) > 1 else None
             out, bn = s['out'], s['bn']
             h, w = s['in_hw']
+            if s is last and ray is not None:
+                ray_w, image = ray
+                check(L.rnr_conv2d_ray(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
+                                       _ptr(s['packed']), _ptr(ray_w), _ptr(self.out_bias), _ptr(image), n, h, w,
+                                       _ptr(mask), st))
+                continue
             if self.fused:
                 check(L.rnr_conv2d_fused(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
                                          _ptr(s['packed']), _ptr(out.data), ctypes.byref(s['cbn']) if s['cbn'] else None, n, h, w,

@@ -433,6 +433,39 @@ def test_calls_in_flight_give_the_sequential_frames():
         mk(inflight=2, streams=2)
 
 
+@pytest.mark.parametrize('skip', [False, True])
+def test_ray_renderer_in_the_out_layer_epilogue(skip):
+    """RNRPipeline(fuse_ray=True): ops.ray_weights + rnr_conv2d_ray (bias + tanh + the 26-ray sum in the out layer's epilogue,
+    straight from the MFMA accumulators) against the separate ray_render_kernel: frames equal to 1e-6 (summation order), with
+    and without dead-tile elimination (skipped tiles are written as zeros), batch of 3 on a plan for 4; the oracle agrees.
+    Measured slower than the separate kernel, hence opt-in."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene, testing
+    from rnr_amd._lib import RnrError
+    from rnr_amd.pipeline import RNRPipeline
+    S = 160
+    sc = testing.tiny_scene(img_size=S, nf0=8, tex_size=64, tex_ch=24, nlat=31, nlon=62, seed=12)
+    mk = lambda **kw: RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], sc['lp'], nf0=8,
+                                  max_views=4, device=DEV, skip_background_tiles=skip, **kw)
+    views = {k: T(v) for k, v in scene.spiral_views(S, [7, 300, 650]).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    a = (dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'])
+    sep_pipe = mk()
+    sep = sep_pipe.render(*a).clone()
+    fused_pipe = mk(fuse_ray=True)
+    fus = fused_pipe.render(*a).clone()
+    assert float((fus - sep).abs().max()) < 1e-6 and float(sep.abs().max()) > 0.05
+    # fewer views than the plan was built for (here the out layer alone would split K: the epilogue pins it to one slice)
+    a1 = [x[1:2] for x in a]
+    assert float((fused_pipe.render(*a1) - sep_pipe.render(*a1)).abs().max()) < 1e-6
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    ref = orc.render_frame(mesh_t, views, S, sc['textures'], sc['unet_sd'], sc['lp'], sc['pivots_spec'], sc['pivots_diff'])
+    assert orc.psnr(fus.cpu(), ref['image']) > 60.0
+    if not skip:
+        with pytest.raises(RnrError, match='80-column'):                # the emulated out layer has no such epilogue
+            mk(fuse_ray=True, precision='f16x3').render(*a)
+
+
 def test_bad_arguments_raise():
     from rnr_amd import _lib, ops
     with pytest.raises(RuntimeError):
