@@ -35,7 +35,7 @@ class _Act:
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
                  prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None, precision='f32',
-                 update_running_stats=False):
+                 update_running_stats=False, check_finite=False):
         """bn_mode 'batch': BatchNorm2d in train mode with PER-VIEW batch statistics — what test_rnr.py:229-233 forces,
         evaluated the way the reference evaluates it (one view per call); a batch of N poses is N independent frames.
         'batch_all': train-mode BatchNorm2d exactly as torch computes it for ONE call with an [N,C,H,W] input: statistics
@@ -55,6 +55,10 @@ class UNetPlan:
             raise ValueError("bn_mode must be 'batch', 'batch_all' or 'running'")
         self.bn_mode = bn_mode
         self.precision = precision
+        # f16x3 splits activations into fp16 terms: |act(scale * x + shift)| must stay below 65504, which BatchNorm outputs do
+        # but the four un-normalised convolutions of the innermost block need not for exotic weights.  check_finite=True makes
+        # every forward verify (one host synchronisation) that its result holds no inf / NaN — a debugging aid, off by default.
+        self.check_finite = bool(check_finite)
         self.L = _lib.load()
         self.dev = device
         self.N = int(max_views)
@@ -224,7 +228,11 @@ class UNetPlan:
                 if s['sync'] is not None:
                     s['sync'].zero_()
             raise
-        return self.out.data[:n] if ray is None else ray[1]
+        res = self.out.data[:n] if ray is None else ray[1]
+        if self.check_finite and mask is None and not bool(torch.isfinite(res).all()):
+            raise FloatingPointError('UNetPlan(precision=%r): non-finite values in the network output (f16x3 needs activations '
+                                     'below 65504: include/rnr_hip.h, RNR_CONV_F32_EMU_F16X3)' % self.precision)
+        return res
 
     def _run_steps(self, n, mask, L, st, ray=None):
         last = self.steps[-1]

@@ -452,3 +452,19 @@ def test_unet_plan_fused_equals_separate_launches(monkeypatch):
         assert float((a - b)[..., :78].abs().max()) < 2e-6 * max(1.0, float(b[..., :78].abs().max())), n
     torch.cuda.synchronize()
     assert all(int(s['sync'].max()) == 0 for s in fused.steps)
+
+
+def test_f16x3_range_guard_is_available():
+    """UNetPlan(check_finite=True): the debugging aid for the fp16 range of the f16x3 emulation.  Ordinary weights
+    pass; a network input scaled to 1e6 lies beyond 65504 -> inf in the fp16 split of the first layer's operand ->
+    FloatingPointError instead of silent NaN frames (the exact-fp32 plan takes the same input without complaint)."""
+    from rnr_amd import ops, testing
+    from rnr_amd.unet import UNetPlan
+    sd = testing.unet_state_dict(16, 8, 16, seed=21, use_gcn=False)
+    x = torch.randn(1, 16, 64, 64, generator=torch.Generator().manual_seed(9))
+    plan = UNetPlan(sd, 16, 8, 16, 5, (64, 64), 1, torch.device(DEV), precision='f16x3', check_finite=True)
+    plan.forward(ops.nchw_to_nhwc(x.to(DEV), plan.in_c_pad))
+    with pytest.raises(FloatingPointError):
+        plan.forward(ops.nchw_to_nhwc((x * 1e6).to(DEV), plan.in_c_pad))
+    exact = UNetPlan(sd, 16, 8, 16, 5, (64, 64), 1, torch.device(DEV), check_finite=True)
+    exact.forward(ops.nchw_to_nhwc((x * 1e6).to(DEV), exact.in_c_pad))
