@@ -257,6 +257,14 @@ typedef struct rnr_conv_desc {
  * the two flags are mutually exclusive. */
 #define RNR_CONV_F32_EMU_F16X3 4
 #define RNR_CONV_F32_EMU_ANY (RNR_CONV_F32_EMU_BF16X6 | RNR_CONV_F32_EMU_F16X3)
+/* Winograd F(2x2, 3x3) for the 3x3 convolutions (Lavin & Gray 2016): fp32 operands and fp32 accumulation on
+ * v_mfma_f32_32x32x2_f32 like the direct kernels, 16 multiplications per 2 x 2 output tile instead of 36.  The transforms
+ * only add and halve; the result differs from the direct convolution by rounding of the order of a different summation
+ * order (tests/test_gpu_unet.py: <= 4e-6 of the output scale on every U-Net layer shape).  Must be set both when packing the
+ * weights (the transformed image is stored behind the direct one) and when convolving; layers it does not cover (other
+ * kinds, maps that do not tile into 16 x 16 pixels, column counts that are not multiples of 64, masked launches, too few
+ * tiles to fill the chip) run the direct kernels from the same buffer.  Not combined with the emulation flags. */
+#define RNR_CONV_WINOGRAD 8
 
 /* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
 size_t rnr_packed_weight_floats(const rnr_conv_desc* d);

@@ -75,6 +75,7 @@ struct ConvParams {
     int src_act[2];
     const float* weight;
     const void* weight_emu;     // bf16x6 image of the same weights (conv_halo_emu_kernel), or NULL
+    const float* weight_wino;   // Winograd-transformed image of the same weights (conv_wino_kernel), or NULL
     float* out;
     double* stats;
     int N, H, W;        // input spatial size
@@ -1707,6 +1708,8 @@ pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __res
         packed[(((chunk * NT + t) * 2 + (k >> 3)) * (long)wstride + co) * 8 + (k & 7)] = (unsigned short)(term[t] & 0xffffu);
 }
 
+#include "conv_wino.inc"
+
 // mask[tile] = any(alpha > 0) over the 32 x th output pixels of the tile (tile order = the halo kernels' mt index)
 __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restrict__ alpha, uint8_t* __restrict__ mask, int H,
                                                           int W, int th) {
@@ -1724,6 +1727,7 @@ __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restric
 
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
+    int wino;       // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 16 pixel tiles x 64 columns)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
     int tw;         // pixel-tile width of the halo plan: 32, or 16 (maps 16 pixels wide)
@@ -1736,7 +1740,12 @@ __global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, l
     if (i < n) p[i] = 0.0;
 }
 
+#ifndef RNR_WINO_MIN_WGS
+#define RNR_WINO_MIN_WGS 192         // fewer 16 x 16 x 64 tiles than this: the direct kernels (they split K)
+#endif
+
 static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
+    p->wino = 0;
     p->taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : (d->kind == RNR_CONV4x4S2_REFLECT ? 16 : 4);
     p->par = d->kind == RNR_CONVT4x4S2 ? 4 : 1;
     if (d->kind == RNR_CONV3x3_REFLECT) { p->Ho = H; p->Wo = W; p->OH = H; p->OW = W; }
@@ -1846,6 +1855,19 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         if (sk < 1) sk = 1;
     }
     p->splitk = sk;
+    // Winograd F(2x2, 3x3): every 3x3 layer whose map tiles into 16 x 16 pixels and whose columns into 64s, when there are
+    // enough tiles to give every CU one (RNR_WINO_MIN_WGS in the environment overrides; 0 in RNR_WINOGRAD disables)
+    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && H % WINO_T == 0 && W % WINO_T == 0 &&
+        d->c_out_pad % WINO_BN == 0 && view_elems < (1L << 30)) {
+        static const int min_wgs = [] { const char* e = getenv("RNR_WINO_MIN_WGS"); return e ? atoi(e) : RNR_WINO_MIN_WGS; }();
+        const long wgs = (long)N * (H / WINO_T) * (W / WINO_T) * (d->c_out_pad / WINO_BN);
+        if (wgs >= min_wgs) {
+            p->wino = 1; p->halo = 1; p->cfg = 0; p->tw = WINO_T; p->bm = WINO_T * WINO_T; p->bn = WINO_BN;
+            p->mtiles = N * (H / WINO_T) * (W / WINO_T);
+            p->ntiles = d->c_out_pad / WINO_BN;
+            p->splitk = 1;
+        }
+    }
     return 0;
 }
 
@@ -1903,9 +1925,11 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
                 "%s: c_in1 %d / pad %d", who, d->c_in1, d->c_in1_pad);
     RNR_REQUIRE(d->c_out > 0 && d->c_out_pad >= d->c_out && d->c_out_pad % BK == 0,
                 "%s: c_out %d / pad %d", who, d->c_out, d->c_out_pad);
-    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_ANY)) == 0, "%s: unknown flags 0x%x", who,
+    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_ANY | RNR_CONV_WINOGRAD)) == 0, "%s: unknown flags 0x%x", who,
                 d->flags);
     RNR_REQUIRE((d->flags & RNR_CONV_F32_EMU_ANY) != RNR_CONV_F32_EMU_ANY, "%s: choose ONE emulation format", who);
+    RNR_REQUIRE(!(d->flags & RNR_CONV_WINOGRAD) || !(d->flags & RNR_CONV_F32_EMU_ANY),
+                "%s: RNR_CONV_WINOGRAD is an exact-fp32 algorithm, not combined with the emulation formats", who);
     return 0;
 }
 
@@ -1913,6 +1937,9 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
 
 using namespace rnr;
 
+static size_t wino_weight_floats(const rnr_conv_desc* d) {
+    return (size_t)16 * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
+}
 static size_t packed_f32_floats(const rnr_conv_desc* d) {
     const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : 16;          // 16 = 4x4 taps, or 4 parity classes x 4 taps
     return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
@@ -1924,6 +1951,8 @@ extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
     // emulation image behind the fp32 image: 64-byte header + 3 bf16 terms (6 bytes) or 2 fp16 terms (4 bytes) per weight
     if (d->flags & RNR_CONV_F32_EMU_BF16X6) return f32 + EMU_HEADER_BYTES / 4 + (f32 * 6 + 3) / 4;
     if (d->flags & RNR_CONV_F32_EMU_F16X3) return f32 + EMU_HEADER_BYTES / 4 + f32;
+    // Winograd image behind the fp32 image: 16 planes instead of 9 taps
+    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT) return f32 + wino_weight_floats(d);
     return f32;
 }
 
@@ -1949,6 +1978,12 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
             hipLaunchKernelGGL(pack_weight_emu_kernel<0>, grid, dim3(256), 0, as_stream(stream), *d, weight, image, total);
         }
         return check_launch("pack_weight_emu_kernel");
+    }
+    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT) {
+        const long nw = (long)wino_weight_floats(d);
+        hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
+                           weight, packed + total, nw);
+        return check_launch("pack_weight_wino_kernel");
     }
     return 0;
 }
@@ -2000,7 +2035,7 @@ extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int
     if (!d || num_views <= 0 || d->kind != RNR_CONV3x3_REFLECT) return 0;
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
-    return (pl.halo && pl.tw == 32 && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
+    return (pl.halo && !pl.wino && pl.tw == 32 && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
 }
 
 extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha, uint8_t* tile_mask, int num_views,
@@ -2039,6 +2074,11 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     hipStream_t st = as_stream(stream);
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
+    if (pl.wino && (tile_mask || g_ray.w)) {    // masked / ray-epilogue launches run on the direct kernels' tiles
+        rnr_conv_desc dd = *d;
+        dd.flags &= ~RNR_CONV_WINOGRAD;
+        make_plan(&dd, num_views, in_h, in_w, &pl);
+    }
     if (g_ray.w) pl.splitk = 1;         // the ray-renderer epilogue needs the whole K sum in one workgroup (small maps would split)
     ConvParams P = {};
     P.src_data[0] = src0->data; P.src_scale[0] = src0->scale; P.src_shift[0] = src0->shift;
@@ -2131,6 +2171,10 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
         if (d->kind == RNR_CONV4x4S2_REFLECT) { if (f16) launch_halo_emu<1, 1>(pl, grid, P, st); else launch_halo_emu<0, 1>(pl, grid, P, st); }
         else if (d->kind == RNR_CONV3x3_REFLECT) { if (f16) launch_halo_emu<1, 0>(pl, grid, P, st); else launch_halo_emu<0, 0>(pl, grid, P, st); }
         else { if (f16) launch_halo_emu<1, 2>(pl, grid, P, st); else launch_halo_emu<0, 2>(pl, grid, P, st); }
+    }
+    else if (pl.wino) {
+        P.weight_wino = weight_packed + packed_f32_floats(d);
+        launch_wino(dim3((unsigned)grid_wgs), P, st);
     }
     else if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
     else if (pl.halo && d->kind == RNR_CONV4x4S2_REFLECT) launch_halo<1>(pl, P, st);
