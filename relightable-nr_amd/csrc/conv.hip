@@ -1727,7 +1727,7 @@ __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restric
 
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
-    int wino;       // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 16 pixel tiles x 64 columns)
+    int wino;       // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 8 pixel tiles x 64 columns)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
     int tw;         // pixel-tile width of the halo plan: 32, or 16 (maps 16 pixels wide)
@@ -1741,7 +1741,7 @@ __global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, l
 }
 
 #ifndef RNR_WINO_MIN_WGS
-#define RNR_WINO_MIN_WGS 192         // fewer 16 x 16 x 64 tiles than this: the direct kernels (they split K)
+#define RNR_WINO_MIN_WGS 256         // fewer 16 x 8 pixel x 64 column tiles than this: the direct kernels (they split K)
 #endif
 
 static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
@@ -1856,14 +1856,14 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     }
     p->splitk = sk;
     // Winograd F(2x2, 3x3): every 3x3 layer whose map tiles into 16 x 16 pixels and whose columns into 64s, when there are
-    // enough tiles to give every CU one (RNR_WINO_MIN_WGS in the environment overrides; 0 in RNR_WINOGRAD disables)
-    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && H % WINO_T == 0 && W % WINO_T == 0 &&
+    // enough tiles to give every CU two (RNR_WINO_MIN_WGS in the environment overrides; 0 in RNR_WINOGRAD disables)
+    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && H % WINO_PH == 0 && W % WINO_PW == 0 &&
         d->c_out_pad % WINO_BN == 0 && view_elems < (1L << 30)) {
         static const int min_wgs = [] { const char* e = getenv("RNR_WINO_MIN_WGS"); return e ? atoi(e) : RNR_WINO_MIN_WGS; }();
-        const long wgs = (long)N * (H / WINO_T) * (W / WINO_T) * (d->c_out_pad / WINO_BN);
+        const long wgs = (long)N * (H / WINO_PH) * (W / WINO_PW) * (d->c_out_pad / WINO_BN);
         if (wgs >= min_wgs) {
-            p->wino = 1; p->halo = 1; p->cfg = 0; p->tw = WINO_T; p->bm = WINO_T * WINO_T; p->bn = WINO_BN;
-            p->mtiles = N * (H / WINO_T) * (W / WINO_T);
+            p->wino = 1; p->halo = 1; p->cfg = 0; p->tw = WINO_PW; p->bm = WINO_PW * WINO_PH; p->bn = WINO_BN;
+            p->mtiles = N * (H / WINO_PH) * (W / WINO_PW);
             p->ntiles = d->c_out_pad / WINO_BN;
             p->splitk = 1;
         }
