@@ -1937,8 +1937,10 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
 
 using namespace rnr;
 
-static size_t wino_weight_floats(const rnr_conv_desc* d) {
-    return (size_t)16 * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
+static size_t wino_weight_floats(const rnr_conv_desc* d) {       // 0: this convolution has no Winograd image
+    if (!(d->flags & RNR_CONV_WINOGRAD) || d->kind != RNR_CONV3x3_REFLECT || d->c_out_pad % WINO_BN != 0) return 0;
+    const size_t nsteps = (size_t)(d->c_in0_pad + d->c_in1_pad) / 2;
+    return (size_t)(d->c_out_pad / WINO_BN) * (nsteps + WINO_BDIST) * WINO_STEP_FLOATS;
 }
 static size_t packed_f32_floats(const rnr_conv_desc* d) {
     const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : 16;          // 16 = 4x4 taps, or 4 parity classes x 4 taps
@@ -1952,8 +1954,7 @@ extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
     if (d->flags & RNR_CONV_F32_EMU_BF16X6) return f32 + EMU_HEADER_BYTES / 4 + (f32 * 6 + 3) / 4;
     if (d->flags & RNR_CONV_F32_EMU_F16X3) return f32 + EMU_HEADER_BYTES / 4 + f32;
     // Winograd image behind the fp32 image: 16 planes instead of 9 taps
-    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT) return f32 + wino_weight_floats(d);
-    return f32;
+    return f32 + wino_weight_floats(d);
 }
 
 extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream) {
@@ -1979,7 +1980,7 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
         }
         return check_launch("pack_weight_emu_kernel");
     }
-    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT) {
+    if (wino_weight_floats(d)) {
         const long nw = (long)wino_weight_floats(d);
         hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
                            weight, packed + total, nw);

@@ -47,7 +47,8 @@ class _Slot:
 class RNRPipeline:
     def __init__(self, mesh, img_size, textures, unet_state_dict, pivots_spec, pivots_diff, lp, nf0, num_down=5,
                  sh_start_ch=6, max_views=1, device='cuda:0', near=0.0, far=1e5, global_RT=None, sh_coeff=None, sh_lmax=10,
-                 skip_background_tiles=True, streams=1, precision='f32', inflight=1, fuse_ray=False):
+                 skip_background_tiles=True, streams=1, precision='f32', inflight=1, fuse_ray=False,
+                 conv_algo=None):
         """
         mesh: dict v/vt/vn/f_v_idx/f_vt_idx/f_vn_idx (numpy or torch; global_RT applied here if given, as
               network.Rasterizer.__init__ does, network.py:126-128)
@@ -91,10 +92,10 @@ class RNRPipeline:
         lane_views = (self.max_views + self.n_streams - 1) // self.n_streams
         self.unet = UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
                              (self.S, self.S), lane_views if self.n_streams > 1 else self.max_views, self.dev,
-                             precision=precision)
+                             precision=precision, conv_algo=conv_algo)
         self._lane_unets = [self.unet] + [UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0, num_down,
                                                    (self.S, self.S), lane_views, self.dev, share_weights_with=self.unet,
-                                                   precision=precision)
+                                                   precision=precision, conv_algo=conv_algo)
                                           for _ in range(self.n_streams - 1)]
         self._lane_streams = ops.side_streams(self.dev, self.n_streams) if self.n_streams > 1 else []
         self.sh_lighting, self.sh_coeff = None, None
@@ -131,7 +132,7 @@ class RNRPipeline:
             sl.stream = slot_streams[i]
             sl.unet = self.unet if i == 0 else UNetPlan(unet_state_dict, self.c_in, 3 * (self.n_spec + self.n_diff), nf0,
                                                         num_down, (S, S), N, self.dev, share_weights_with=self.unet,
-                                                        precision=precision)
+                                                        precision=precision, conv_algo=conv_algo)
             sl.ws = self._lane_ws[0] if i == 0 else torch.empty_like(self._lane_ws[0])
             sl.gb = self._gb if i == 0 else {m: torch.empty_like(t) for m, t in self._gb.items()}
             sl.net_in = self._net_in if i == 0 else torch.empty_like(self._net_in)

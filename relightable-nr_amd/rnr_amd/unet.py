@@ -32,10 +32,13 @@ class _Act:
         self.shift = None
 
 
+DEFAULT_CONV_ALGO = 'direct'
+
+
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
                  prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None, precision='f32',
-                 update_running_stats=False, check_finite=False):
+                 update_running_stats=False, check_finite=False, conv_algo=None):
         """bn_mode 'batch': BatchNorm2d in train mode with PER-VIEW batch statistics — what test_rnr.py:229-233 forces,
         evaluated the way the reference evaluates it (one view per call); a batch of N poses is N independent frames.
         'batch_all': train-mode BatchNorm2d exactly as torch computes it for ONE call with an [N,C,H,W] input: statistics
@@ -47,12 +50,22 @@ class UNetPlan:
         cores — operands split into three bf16 terms (exactly; six partial products) or two fp16 terms (22 significand
         bits; three partial products), accumulated in fp32; error of the order of fp32's own rounding, 2.7x / 5.3x fewer
         MFMA cycles (include/rnr_hip.h, RNR_CONV_F32_EMU_BF16X6 / RNR_CONV_F32_EMU_F16X3).
+        conv_algo 'winograd': the 3x3 convolutions run as Winograd F(2x2, 3x3) — fp32 operands and accumulation on the same
+        matrix-core instruction, 2.25x fewer multiplications (include/rnr_hip.h, RNR_CONV_WINOGRAD; 'f32' only) — where the
+        layer shape allows; 'direct': every convolution as a direct implicit GEMM.  None: $RNR_CONV_ALGO, else DEFAULT_CONV_ALGO.
         share_weights_with: another UNetPlan of the same network whose packed weights / BN parameters are reused
         (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
         if precision not in _lib.EMU_FLAGS:
             raise ValueError("precision must be one of %s" % sorted(_lib.EMU_FLAGS))
         if bn_mode not in ('batch', 'batch_all', 'running'):
             raise ValueError("bn_mode must be 'batch', 'batch_all' or 'running'")
+        if conv_algo is None:
+            conv_algo = os.environ.get('RNR_CONV_ALGO') or DEFAULT_CONV_ALGO
+        if conv_algo not in ('direct', 'winograd'):
+            raise ValueError("conv_algo must be 'direct' or 'winograd'")
+        if precision != 'f32':
+            conv_algo = 'direct'        # the emulation kernels have no Winograd form
+        self.conv_algo = conv_algo
         self.bn_mode = bn_mode
         self.precision = precision
         # f16x3 splits activations into fp16 terms: |act(scale * x + shift)| must stay below 65504, which BatchNorm outputs do
@@ -84,6 +97,8 @@ class UNetPlan:
             s1 = srcs[1] if len(srcs) > 1 else None
             desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
             desc.flags |= _lib.EMU_FLAGS[precision]
+            if conv_algo == 'winograd' and kind == CONV3x3_REFLECT:
+                desc.flags |= _lib.CONV_WINOGRAD
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
             else:
