@@ -177,7 +177,7 @@ __device__ __forceinline__ void bn_finalize_views(const ConvParams& P, int n_fir
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.stats, 0, 0x7fffffff, 0x27000);
     const uintx4_t zero4 = {0u, 0u, 0u, 0u};
     typedef double doublex2 __attribute__((ext_vector_type(2)));
-    for (int i = tid; i < total; i += CTHREADS) {
+    for (int i = tid; i < total; i += (int)blockDim.x) {
         const int idx = n_first * P.c_out_pad + i;
         const int c = i % P.c_out_pad;
         doublex2 part[STAT_SHARDS];
@@ -1709,6 +1709,7 @@ pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __res
 }
 
 #include "conv_wino.inc"
+#include "conv_wino2.inc"
 
 // mask[tile] = any(alpha > 0) over the 32 x th output pixels of the tile (tile order = the halo kernels' mt index)
 __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restrict__ alpha, uint8_t* __restrict__ mask, int H,
@@ -1727,7 +1728,8 @@ __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restric
 
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
-    int wino;       // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 8 pixel tiles x 64 columns)
+    int wino;       // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 8 pixel tiles x 64 columns), 2: conv_wino2_kernel (F(2x2, 2x2),
+                    // the 4x4 stride-2 convolutions: 16 x 8 tiles of the GEMM row space x 128 (conv) / 64 (transposed) columns)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
     int tw;         // pixel-tile width of the halo plan: 32, or 16 (maps 16 pixels wide)
@@ -1740,6 +1742,9 @@ __global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, l
     if (i < n) p[i] = 0.0;
 }
 
+#ifndef RNR_WINO2_MIN_WGS
+#define RNR_WINO2_MIN_WGS 200        // fewer workgroups (one per CU) than this: the direct kernels
+#endif
 #ifndef RNR_WINO_MIN_WGS
 #define RNR_WINO_MIN_WGS 256         // fewer 16 x 8 pixel x 64 column tiles than this: the direct kernels (they split K)
 #endif
@@ -1855,16 +1860,32 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         if (sk < 1) sk = 1;
     }
     p->splitk = sk;
-    // Winograd F(2x2, 3x3): every 3x3 layer whose map tiles into 16 x 16 pixels and whose columns into 64s, when there are
-    // enough tiles to give every CU two (RNR_WINO_MIN_WGS in the environment overrides; 0 in RNR_WINOGRAD disables)
+    // Winograd F(2x2, 3x3): every 3x3 layer whose map tiles into 16 x 8 pixels and whose columns into 64s, when there are
+    // enough tiles to give every CU two (RNR_WINO_MIN_WGS in the environment overrides)
+    static const int min_wgs = [] { const char* e = getenv("RNR_WINO_MIN_WGS"); return e ? atoi(e) : RNR_WINO_MIN_WGS; }();
     if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && H % WINO_PH == 0 && W % WINO_PW == 0 &&
         d->c_out_pad % WINO_BN == 0 && view_elems < (1L << 30)) {
-        static const int min_wgs = [] { const char* e = getenv("RNR_WINO_MIN_WGS"); return e ? atoi(e) : RNR_WINO_MIN_WGS; }();
         const long wgs = (long)N * (H / WINO_PH) * (W / WINO_PW) * (d->c_out_pad / WINO_BN);
         if (wgs >= min_wgs) {
             p->wino = 1; p->halo = 1; p->cfg = 0; p->tw = WINO_PW; p->bm = WINO_PW * WINO_PH; p->bn = WINO_BN;
             p->mtiles = N * (H / WINO_PH) * (W / WINO_PW);
             p->ntiles = d->c_out_pad / WINO_BN;
+            p->splitk = 1;
+        }
+    }
+    // Winograd F(2x2, 2x2) for the 4x4 stride-2 convolutions: 16 x 16 output pixels x 128 columns (convolution) or the four
+    // parity classes of 16 x 8 input pixels x 64 columns (transposed) per workgroup
+    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind != RNR_CONV3x3_REFLECT && p->Wo % WINO_PW == 0 &&
+        p->Ho % (d->kind == RNR_CONVT4x4S2 ? WINO_PH : 16) == 0 && d->c_out_pad % (d->kind == RNR_CONVT4x4S2 ? 64 : 128) == 0 &&
+        view_elems < (1L << 30)) {
+        const int bnw = d->kind == RNR_CONVT4x4S2 ? 64 : 128, tph = d->kind == RNR_CONVT4x4S2 ? WINO_PH : 16;
+        const long wgs = (long)N * (p->Ho / tph) * (p->Wo / WINO_PW) * (d->c_out_pad / bnw);
+        static const int min_wgs2 = [] { const char* e = getenv("RNR_WINO2_MIN_WGS"); return e ? atoi(e) : RNR_WINO2_MIN_WGS; }();
+        if (wgs >= min_wgs2) {
+            p->wino = 2; p->halo = 1; p->cfg = 0; p->tw = WINO_PW; p->bm = WINO_PW * tph; p->bn = bnw;
+            p->mtiles = N * (p->Ho / tph) * (p->Wo / WINO_PW);
+            p->ntiles = d->c_out_pad / bnw;
+            p->par = 1;
             p->splitk = 1;
         }
     }
@@ -1938,9 +1959,13 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
 using namespace rnr;
 
 static size_t wino_weight_floats(const rnr_conv_desc* d) {       // 0: this convolution has no Winograd image
-    if (!(d->flags & RNR_CONV_WINOGRAD) || d->kind != RNR_CONV3x3_REFLECT || d->c_out_pad % WINO_BN != 0) return 0;
-    const size_t nsteps = (size_t)(d->c_in0_pad + d->c_in1_pad) / 2;
-    return (size_t)(d->c_out_pad / WINO_BN) * (nsteps + WINO_BDIST) * WINO_STEP_FLOATS;
+    if (!(d->flags & RNR_CONV_WINOGRAD)) return 0;
+    const size_t npairs = (size_t)(d->c_in0_pad + d->c_in1_pad) / 2;       // K steps per tap set
+    if (d->kind == RNR_CONV3x3_REFLECT)
+        return d->c_out_pad % WINO_BN ? 0 : (size_t)(d->c_out_pad / WINO_BN) * (npairs + WINO_BDIST) * WINO_STEP_FLOATS;
+    if (d->kind == RNR_CONVT4x4S2)
+        return d->c_out_pad % 64 ? 0 : (size_t)(d->c_out_pad / 64) * (npairs + W2_BDIST) * w2_step_floats<2>();
+    return d->c_out_pad % 128 ? 0 : (size_t)(d->c_out_pad / 128) * (4 * npairs + W2_BDIST) * w2_step_floats<1>();     // four phases
 }
 static size_t packed_f32_floats(const rnr_conv_desc* d) {
     const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : 16;          // 16 = 4x4 taps, or 4 parity classes x 4 taps
@@ -1982,8 +2007,12 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
     }
     if (wino_weight_floats(d)) {
         const long nw = (long)wino_weight_floats(d);
-        hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
-                           weight, packed + total, nw);
+        if (d->kind == RNR_CONV3x3_REFLECT)
+            hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
+                               weight, packed + total, nw);
+        else
+            hipLaunchKernelGGL(pack_weight_wino2_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
+                               weight, packed + total, nw);
         return check_launch("pack_weight_wino_kernel");
     }
     return 0;
@@ -2175,7 +2204,10 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     }
     else if (pl.wino) {
         P.weight_wino = weight_packed + packed_f32_floats(d);
-        launch_wino(dim3((unsigned)grid_wgs), P, st);
+        P.par_inner = 0;
+        if (pl.wino == 1) launch_wino(dim3((unsigned)grid_wgs), P, st);
+        else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
+        else launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);
     }
     else if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
     else if (pl.halo && d->kind == RNR_CONV4x4S2_REFLECT) launch_halo<1>(pl, P, st);
