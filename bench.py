@@ -50,6 +50,9 @@ def parse(argv=None):
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6', 'f16x3'],
                     help="conv arithmetic of the timed loop: exact fp32 MFMA (default, the headline) or fp32 emulated on the bf16 "
                          "matrix cores (RNR_CONV_F32_EMU_BF16X6)")
+    ap.add_argument('--conv-algo', default=None, choices=['winograd', 'direct'],
+                    help='U-Net convolution algorithm (rnr_amd.unet.UNetPlan conv_algo; default: the library default, winograd — '
+                         'fp32 Winograd F(2x2,3x3) / F(2x2,2x2) on the f32 MFMA; direct = every layer as a direct implicit GEMM)')
     ap.add_argument('--pmc-file', default=None,
                     help='merged.json written by scripts/pmc.sh (rocprofv3 --pmc passes over THIS command line at the same '
                          '--views-per-step / --precision): source of roofline.traffic.  Without it the newest committed '
@@ -259,10 +262,26 @@ def sustained_block(precision, achieved_tf):
                 src, ins, rates[ins], '' if products == 1 else ' (/ %d partial products)' % products)}
 
 
+def algo_block(unet, n_views, stage_ms, peak, masked_out_layer):
+    """What the matrix cores execute beside the algorithmic (direct-form) figure of a roofline block."""
+    ex = unet.mfma_flops_per_view(n_views, masked_out_layer) * n_views
+    tf = ex / (stage_ms * 1e-3) / 1e12
+    algos = [unet.L.rnr_conv_algorithm(ctypes.byref(s['desc']), n_views, *s['in_hw']) for s in unet.steps]
+    if masked_out_layer:
+        algos[-1] = 0
+    return {'conv_algo': unet.conv_algo,
+            'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1), algos.count(2)],
+            'executed_mfma_flops': ex, 'executed_tflops': tf, 'frac_executed': tf / peak,
+            'algo_note': "achieved / frac count the ALGORITHMIC FLOPs of the convolutions (direct form, SURVEY 8(d)); with "
+                         "conv_algo 'winograd' the 3x3 layers execute 16 instead of 36 multiplications per 2x2 outputs and the "
+                         "4x4 stride-2 ones 9 instead of 16 (fp32 operands, fp32 accumulation, same MFMA instruction), so frac "
+                         "can exceed 1; executed_tflops / frac_executed = what the matrix cores actually run against the same peak"}
+
+
 def make_pipeline(sc, args, dev, V, **kw):
     from rnr_amd.pipeline import RNRPipeline
     opts = dict(nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10,
-                skip_background_tiles=args.tile_skip, precision=args.precision)
+                skip_background_tiles=args.tile_skip, precision=args.precision, conv_algo=args.conv_algo)
     opts.update(kw)
     return RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, **opts)
 
@@ -327,6 +346,7 @@ def single_view_block(sc, args, dev):
     dt_fly = (time.perf_counter() - t0) / n1
     same = float((hs.image - seq_last).abs().max())
     flops_view = pipe.unet.flops_per_view
+    algo1 = algo_block(pipe.unet, 1, unet_ms, EMU_PEAK[args.precision], args.tile_skip) if args.precision == 'f32' else {}
     del pipe
     # ... and three (one more private stream / activation set; a fourth would share a hardware queue: slower again)
     pipe3 = make_pipeline(sc, args, dev, 1, inflight=3)
@@ -347,11 +367,11 @@ def single_view_block(sc, args, dev):
         'views_per_call': 1, 'views': n1,
         'workload': 'test_rnr.py:265-393: spiral_step720 views in order, one view per call, %dx%d, full HIP RenderingNet' % (args.img_size, args.img_size),
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
                                                   '64^2 -> 32^2 stride-2 layer; everywhere else the BatchNorm finalise and the split-K combine '
                                                   'happen inside the conv launch; HIP events bracket the U-Net stage of every call)',
                      'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'stage_ms_per_view': unet_ms,
-                     **sustained_block(args.precision, tf),
+                     **algo1, **sustained_block(args.precision, algo1.get('executed_tflops', tf)),
                      'alg_flops_per_view': flops_view, 'traffic': traffic,
                      'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)', **tinfo},
         'two_calls_in_flight': {'frames_per_s': 1.0 / dt_fly, 'ms_per_frame': dt_fly * 1e3,
@@ -480,6 +500,7 @@ def main(argv=None):
         n_conv = len(pipe.unet.steps)
     achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
     peak_tf = EMU_PEAK[args.precision]
+    algo8 = algo_block(pipe.unet, V, unet_ms, peak_tf, args.tile_skip) if (not stub and args.precision == 'f32') else {}
     dtype = {'f32': 'f32', 'bf16x6': 'f32 emulated on bf16 MFMA (bf16x6)', 'f16x3': 'f32 emulated on f16 MFMA (f16x3)'}[args.precision]
 
     res = None
@@ -502,13 +523,13 @@ def main(argv=None):
                                    'levels, U-Net %d->%d nf0=%d' % (V, args.img_size, args.img_size, args.tex_ch, sc['c_in'],
                                                                    3 * sc['n_rays'], args.nf0),
                        'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world},
-            'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
+            'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
                          'achieved': achieved_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / peak_tf, 'traffic': traffic,
+                         'frac': achieved_tf / peak_tf, **algo8, 'traffic': traffic,
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
                          **traffic_info,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
-                         **sustained_block(args.precision, achieved_tf),
+                         **sustained_block(args.precision, algo8.get('executed_tflops', achieved_tf)),
                          'out_layer_tiles_skipped': skipped,
                          'flops_note': 'executed FLOPs = %.1f GFLOP/view live U-Net minus the out-layer pixel tiles that hold no '
                                        'foreground pixel when --tile-skip is given (never read: the ray renderer zeroes background)'
@@ -587,6 +608,27 @@ def main(argv=None):
                                                        'ms_per_step': dt2 / args.steps * 1e3,
                                                        'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
                 del pipe2
+        if extras and not fast and world == 1 and args.precision == 'f32' and pipe.unet.conv_algo == 'winograd':
+            # every convolution as a direct implicit GEMM (the r01 - r03 path: conv_halo_kernel only), same frames to fp32 rounding
+            try:
+                pd = make_pipeline(sc, args, dev, V, conv_algo='direct')
+                restore_d = hook_unet_events(pd.unet, args.steps + 2)
+                dtd = timed(pd)
+                ums = restore_d()
+                tfd = pd.unet.flops_per_view * V / (ums * 1e-3) / 1e12
+                lo = (args.warmup + args.steps - 1) * V
+                sl = slice(lo, lo + V)
+                dimg = pd.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+                wimg = pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+                res['with_direct_convolutions'] = {
+                    'frames_per_s': args.steps * V / dtd, 'ms_per_step': dtd / args.steps * 1e3,
+                    'max_abs_diff_vs_headline_frames': float((dimg - wimg).abs().max()),
+                    'roofline': {'bound': 'mfma', 'kernel': 'conv_halo_kernel (U-Net stage, HIP events)', 'achieved': tfd, 'peak': peak_tf,
+                                 'unit': 'TFLOP/s', 'frac': tfd / peak_tf, 'stage_ms_per_step': ums, **sustained_block('f32', tfd)},
+                    'note': "RNRPipeline(conv_algo='direct'): every layer a direct implicit GEMM on the f32 MFMA; not the headline value"}
+                del pd
+            except Exception as e:          # noqa: BLE001 - an extra must never fail the bench line
+                res['with_direct_convolutions'] = {'error': str(e)[:200]}
         if extras and not fast and world == 1:
             # the same steps with two of them in flight (RNRPipeline(inflight=2).submit: private activations per slot, the
             # non-conv stages and kernel tails of one step run under the convolutions of the other); full compute, same frames

@@ -257,13 +257,16 @@ typedef struct rnr_conv_desc {
  * the two flags are mutually exclusive. */
 #define RNR_CONV_F32_EMU_F16X3 4
 #define RNR_CONV_F32_EMU_ANY (RNR_CONV_F32_EMU_BF16X6 | RNR_CONV_F32_EMU_F16X3)
-/* Winograd F(2x2, 3x3) for the 3x3 convolutions (Lavin & Gray 2016): fp32 operands and fp32 accumulation on
- * v_mfma_f32_32x32x2_f32 like the direct kernels, 16 multiplications per 2 x 2 output tile instead of 36.  The transforms
- * only add and halve; the result differs from the direct convolution by rounding of the order of a different summation
- * order (tests/test_gpu_unet.py: <= 4e-6 of the output scale on every U-Net layer shape).  Must be set both when packing the
- * weights (the transformed image is stored behind the direct one) and when convolving; layers it does not cover (other
- * kinds, maps that do not tile into 16 x 16 pixels, column counts that are not multiples of 64, masked launches, too few
- * tiles to fill the chip) run the direct kernels from the same buffer.  Not combined with the emulation flags. */
+/* Winograd minimal filtering (Lavin & Gray 2016): F(2x2, 3x3) for the 3x3 convolutions — 16 multiplications per 2 x 2
+ * output tile instead of 36 — and F(2x2, 2x2) for the two 4x4 stride-2 convolutions, which are sums of 2x2-tap correlations
+ * (per input parity phase resp. per output parity class) — 9 instead of 16.  fp32 operands and fp32 accumulation on
+ * v_mfma_f32_32x32x2_f32 like the direct kernels; the data transforms only add (F(2x2, 3x3) also halves weights), so the
+ * result differs from the direct convolution by rounding of the order of a different summation order (scripts/wino_check.py,
+ * tests/test_gpu_unet.py: max error against a float64 convolution <= 1.1e-5 of the output rms on every U-Net layer shape,
+ * direct <= 8.6e-6).  Must be set both when packing the weights (the transformed image is stored behind the direct one) and
+ * when convolving; calls it does not cover (maps that do not tile into 16 x 8 / 16 x 16 pixels, column counts that are not
+ * multiples of 64 / 128, masked launches, too few tiles to fill the chip: rnr_conv_algorithm tells) run the direct kernels
+ * from the same buffer.  Not combined with the emulation flags. */
 #define RNR_CONV_WINOGRAD 8
 
 /* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
@@ -271,6 +274,11 @@ size_t rnr_packed_weight_floats(const rnr_conv_desc* d);
 /* PyTorch layout -> packed.  Conv2d weight [c_out, c_in0 + c_in1, kh, kw] (pytorch_prototyping.py:116, 250-268);
  * ConvTranspose2d weight [c_in0 + c_in1, c_out, 4, 4] (pytorch_prototyping.py:154-159). */
 int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream);
+
+/* Which algorithm rnr_conv2d* runs for (desc, N, input H, input W): 0 = direct implicit GEMM, 1 = Winograd F(2x2, 3x3),
+ * 2 = Winograd F(2x2, 2x2) (16 multiplications per 2 x 2 outputs instead of 36, resp. 9 instead of 16); -1 = bad arguments.
+ * Non-zero only with RNR_CONV_WINOGRAD in desc->flags.  Masked launches (tile_mask != NULL) and rnr_conv2d_ray always run 0. */
+int rnr_conv_algorithm(const rnr_conv_desc* d, int num_views, int in_h, int in_w);
 
 /* Scratch bytes rnr_conv2d may need for (desc, N, input H, input W) (split-K partial slabs). */
 size_t rnr_conv_workspace_bytes(const rnr_conv_desc* d, int num_views, int in_h, int in_w);

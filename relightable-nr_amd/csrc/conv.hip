@@ -2061,6 +2061,13 @@ extern "C" size_t rnr_conv_sync_bytes(const rnr_conv_desc* d, int max_views, int
     return need;
 }
 
+extern "C" int rnr_conv_algorithm(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
+    if (!d || num_views <= 0 || d->kind < 0 || d->kind > 2) return -1;
+    ConvPlan pl;
+    make_plan(d, num_views, in_h, in_w, &pl);
+    return pl.wino;
+}
+
 extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
     if (!d || num_views <= 0 || d->kind != RNR_CONV3x3_REFLECT) return 0;
     ConvPlan pl;

@@ -84,6 +84,7 @@ SIGNATURES = {
     'rnr_conv2d': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
                            c_int, c_void_p, c_size_t, c_void_p]),
     'rnr_conv_tile_count': (c_size_t, [P(RnrConvDesc), c_int, c_int, c_int]),
+    'rnr_conv_algorithm': (c_int, [P(RnrConvDesc), c_int, c_int, c_int]),
     'rnr_conv_active_tiles': (c_int, [P(RnrConvDesc), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_conv2d_masked': (c_int, [P(RnrConvDesc), P(RnrConvSrc), P(RnrConvSrc), c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_void_p, c_size_t, c_void_p, c_void_p]),

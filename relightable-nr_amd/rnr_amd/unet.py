@@ -32,7 +32,7 @@ class _Act:
         self.shift = None
 
 
-DEFAULT_CONV_ALGO = 'direct'
+DEFAULT_CONV_ALGO = 'winograd'
 
 
 class UNetPlan:
@@ -50,9 +50,10 @@ class UNetPlan:
         cores — operands split into three bf16 terms (exactly; six partial products) or two fp16 terms (22 significand
         bits; three partial products), accumulated in fp32; error of the order of fp32's own rounding, 2.7x / 5.3x fewer
         MFMA cycles (include/rnr_hip.h, RNR_CONV_F32_EMU_BF16X6 / RNR_CONV_F32_EMU_F16X3).
-        conv_algo 'winograd': the 3x3 convolutions run as Winograd F(2x2, 3x3) — fp32 operands and accumulation on the same
-        matrix-core instruction, 2.25x fewer multiplications (include/rnr_hip.h, RNR_CONV_WINOGRAD; 'f32' only) — where the
-        layer shape allows; 'direct': every convolution as a direct implicit GEMM.  None: $RNR_CONV_ALGO, else DEFAULT_CONV_ALGO.
+        conv_algo 'winograd': the 3x3 convolutions run as Winograd F(2x2, 3x3) and the 4x4 stride-2 ones (both directions) as
+        F(2x2, 2x2) — fp32 operands and accumulation on the same matrix-core instruction, 2.25x / 1.78x fewer multiplications
+        (include/rnr_hip.h, RNR_CONV_WINOGRAD; 'f32' only) — where the layer shape allows; 'direct': every convolution as a
+        direct implicit GEMM.  None: $RNR_CONV_ALGO, else DEFAULT_CONV_ALGO.
         share_weights_with: another UNetPlan of the same network whose packed weights / BN parameters are reused
         (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
         if precision not in _lib.EMU_FLAGS:
@@ -97,7 +98,7 @@ class UNetPlan:
             s1 = srcs[1] if len(srcs) > 1 else None
             desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
             desc.flags |= _lib.EMU_FLAGS[precision]
-            if conv_algo == 'winograd' and kind == CONV3x3_REFLECT:
+            if conv_algo == 'winograd':
                 desc.flags |= _lib.CONV_WINOGRAD
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
@@ -185,6 +186,28 @@ class UNetPlan:
             self.out_bias[:self.out_channels] = g('out_layer.0.net.1.bias')
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.flops_per_view = self._count_flops()
+
+    def mfma_flops_per_view(self, n_views, masked_out_layer=True):
+        """Multiply-add FLOPs the matrix cores execute per view when `n_views` are passed per call: the direct-form count of
+        every convolution (flops_per_view) divided by 2.25 / 1.78 where rnr_conv_algorithm says a Winograd kernel runs (the
+        out layer runs direct when it is tile-masked)."""
+        total = 0.0
+        for i, s in enumerate(self.steps):
+            d, (h, w) = s['desc'], s['in_hw']
+            algo = self.L.rnr_conv_algorithm(ctypes.byref(d), int(n_views), h, w)
+            if masked_out_layer and i == len(self.steps) - 1:
+                algo = 0
+            total += self._layer_flops(d, h, w) / {0: 1.0, 1: 36.0 / 16.0, 2: 16.0 / 9.0}[algo]
+        return total
+
+    @staticmethod
+    def _layer_flops(d, h, w):
+        cin = d.c_in0 + d.c_in1
+        if d.kind == CONV3x3_REFLECT:
+            return 2 * h * w * 9 * cin * d.c_out
+        if d.kind == CONV4x4S2_REFLECT:
+            return 2 * (h // 2) * (w // 2) * 16 * cin * d.c_out
+        return 2 * (2 * h) * (2 * w) * 4 * cin * d.c_out
 
     def _count_flops(self):
         total = 0
