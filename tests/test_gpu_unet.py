@@ -243,6 +243,108 @@ def test_conv_vs_torch(kind, N, H, W, cins, c_out):
     assert torch.allclose(stats[:, :c_out, 1], s2, rtol=1e-4)
 
 
+WINO_CASES = [
+    # kind, N, H, W, [C per source], c_out, algorithm rnr_conv_algorithm must report (0 direct, 1 F(2x2,3x3), 2 F(2x2,2x2));
+    # the Winograd plans need >= 256 (3x3) / >= 200 (4x4 stride 2) workgroups
+    (0, 2, 64, 128, [64], 128, 1),      # 3x3: two column tiles, 8 x 8 pixel tiles per view, reflection on all four borders
+    (0, 2, 128, 128, [108], 64, 1),     # the input layer's channel count (7 chunks, 4 padding channels), one column tile
+    (0, 16, 32, 32, [64, 64], 128, 1),  # skip concat (two sources with their own scale / shift / activation), 16 views
+    (0, 9, 8, 16, [256], 256, 0),       # too few tiles (36 workgroups): the direct kernels
+    (0, 64, 8, 16, [256], 256, 1),      # map = exactly one 16 x 8 tile per view: every halo pixel reflected
+    (0, 2, 128, 128, [64, 64], 78, 0),  # the out layer's 78 columns: not a multiple of 64 -> direct kernels from the same buffer
+    (2, 2, 64, 64, [128], 256, 2),      # transposed: four parity classes on one staged halo, zero border, four column tiles
+    (2, 16, 16, 16, [512], 512, 2),     # layer 12 at 16 views: 2 tiles per view, 32 chunks
+    (2, 16, 32, 64, [64, 64], 64, 2),   # skip concat, non-square, one column tile
+    (2, 1, 16, 16, [512], 512, 0),      # layer 12 at one view: 16 workgroups -> direct (split-K)
+    (1, 4, 256, 256, [16], 128, 2),     # 4x4 s2: four phases per chunk, 16 x 16 output tiles, reflection on all borders
+    (1, 4, 128, 256, [128], 256, 2),    # two column tiles of 128, non-square, 8 chunks x 4 phases
+    (1, 64, 32, 32, [64], 512, 2),      # output = exactly one tile per view
+    (1, 2, 64, 64, [64], 96, 0),        # 96 columns: not a multiple of 128 -> direct
+]
+
+
+@pytest.mark.parametrize('kind,N,H,W,cins,c_out,algo', WINO_CASES)
+def test_conv_winograd_vs_torch(kind, N, H, W, cins, c_out, algo):
+    """RNR_CONV_WINOGRAD (conv_wino_kernel: F(2x2, 3x3); conv_wino2_kernel: F(2x2, 2x2) for the 4x4 stride-2 convolutions) through
+    the product entry point rnr_conv2d_fused against a float64 torch convolution: output, BatchNorm scale / shift from the
+    statistics of the same launch, padding columns, the sync buffer left at zero, and which algorithm the plan reports.
+    Tolerance 3e-5 of the output scale (measured <= 1.1e-5 of the rms; the direct kernels are held to 1e-4)."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(kind * 1000 + H + W + c_out + N)
+    srcs = []
+    for j, C in enumerate(cins):
+        raw = torch.randn(N, C, H, W, generator=g)
+        sc = torch.rand(N, C, generator=g) + 0.5
+        sh = torch.randn(N, C, generator=g) * 0.3
+        srcs.append((raw, sc, sh, 1 if kind != 2 and j == 0 else 2))
+    cin = sum(cins)
+    if kind == 2:
+        w = torch.randn(cin, c_out, 4, 4, generator=g) / (cin * 4) ** 0.5
+    else:
+        k = 3 if kind == 0 else 4
+        w = torch.randn(c_out, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    pad16 = lambda c: (c + 15) // 16 * 16
+    desc = _lib.RnrConvDesc(kind, cins[0], pad16(cins[0]), cins[1] if len(cins) > 1 else 0,
+                            pad16(cins[1]) if len(cins) > 1 else 0, c_out, pad16(c_out), _lib.CONV_WINOGRAD)
+    assert _lib.load().rnr_conv_algorithm(ctypes.byref(desc), N, H, W) == algo
+    desc.flags = 0
+    assert _lib.load().rnr_conv_algorithm(ctypes.byref(desc), N, H, W) == 0
+    gamma, beta = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
+    out, scale, shift, sync = run_conv_fused(kind, srcs, w, c_out, N, H, W, gamma, beta, flags=_lib.CONV_WINOGRAD, repeats=2)
+    ref = ref_conv(kind, srcs, w).permute(0, 2, 3, 1)
+    got = out[..., :c_out].double()
+    assert torch.isfinite(out).all() and int(sync.to(torch.int32).abs().sum()) == 0
+    assert float(out[..., c_out:].abs().max() if out.shape[-1] > c_out else 0.0) == 0.0
+    peak = ref.abs().max()
+    assert (got - ref).abs().max() < 3e-5 * peak, ((got - ref).abs().max(), peak)
+    mean = ref.mean(dim=(1, 2))
+    var = ref.var(dim=(1, 2), unbiased=False)
+    sc_ref = gamma.double()[None] / torch.sqrt(var + 1e-5)
+    sh_ref = beta.double()[None] - mean * sc_ref
+    assert torch.allclose(scale[:, :c_out].double(), sc_ref, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(shift[:, :c_out].double(), sh_ref, rtol=2e-5, atol=2e-5)
+    assert float(scale[:, c_out:].abs().max() if scale.shape[1] > c_out else 0.0) == 0.0
+
+
+def test_conv_winograd_is_run_to_run_stable_and_flag_is_checked():
+    """out_raw of the Winograd kernels is bit-reproducible run to run (fixed summation order; only the statistics are
+    floating-point atomics), and the flag is refused together with an emulation format."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    srcs = [(torch.randn(2, 64, 64, 128, generator=g), torch.rand(2, 64, generator=g) + 0.5, torch.randn(2, 64, generator=g), 1)]
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24.0
+    a = run_conv_fused(0, srcs, w, 128, 2, 64, 128, flags=_lib.CONV_WINOGRAD)[0]
+    b = run_conv_fused(0, srcs, w, 128, 2, 64, 128, flags=_lib.CONV_WINOGRAD)[0]
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match='WINOGRAD'):
+        run_conv_fused(0, srcs, w, 128, 2, 64, 128, flags=_lib.CONV_WINOGRAD | _lib.CONV_F32_EMU_F16X3)
+
+
+def test_unet_plan_winograd_vs_direct():
+    """UNetPlan(conv_algo='winograd') against conv_algo='direct' on a network wide enough for every Winograd kernel to run
+    (the benchmark's nf0 64 at 256 x 256, 8 views): same frames to fp32 rounding, and the plan reports which layers run which
+    algorithm."""
+    from rnr_amd.unet import UNetPlan
+    from rnr_amd.scene import unet_state_dict
+    sd = unet_state_dict(30, 78, 64, 5, seed=3)
+    dev = torch.device(DEV)
+    wino = UNetPlan(sd, 30, 78, 64, 5, (256, 256), 8, dev, conv_algo='winograd')
+    direct = UNetPlan(sd, 30, 78, 64, 5, (256, 256), 8, dev, conv_algo='direct')
+    assert wino.conv_algo == 'winograd' and direct.conv_algo == 'direct'
+    algos = [wino.L.rnr_conv_algorithm(ctypes.byref(s['desc']), 8, *s['in_hw']) for s in wino.steps]
+    assert algos.count(1) >= 8 and algos.count(2) >= 3 and algos[-1] == 0, algos
+    assert all(direct.L.rnr_conv_algorithm(ctypes.byref(s['desc']), 8, *s['in_hw']) == 0 for s in direct.steps)
+    assert wino.mfma_flops_per_view(8) < 0.75 * wino.flops_per_view and direct.mfma_flops_per_view(8) == direct.flops_per_view
+    x = torch.randn(8, 256, 256, wino.in_c_pad, generator=torch.Generator().manual_seed(1)).to(dev)
+    x[..., 30:] = 0
+    a = wino.forward(x).clone()
+    b = direct.forward(x).clone()
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) < 2e-4 * float(b.abs().max())
+    # emulated precisions have no Winograd form: the option is ignored there
+    assert UNetPlan(sd, 30, 78, 64, 5, (64, 64), 1, dev, precision='f16x3', conv_algo='winograd').conv_algo == 'direct'
+
+
 EMU_CASES = [
     (0, 1, 64, 64, [112], 64),         # 256x64 tiles, 7 chunks
     (0, 2, 32, 64, [64, 64], 128),     # 128x128 tiles, skip concat, two views
