@@ -267,10 +267,10 @@ def algo_block(unet, n_views, stage_ms, peak, masked_out_layer):
     ex = unet.mfma_flops_per_view(n_views, masked_out_layer) * n_views
     tf = ex / (stage_ms * 1e-3) / 1e12
     algos = [unet.L.rnr_conv_algorithm(ctypes.byref(s['desc']), n_views, *s['in_hw']) for s in unet.steps]
-    if masked_out_layer:
+    if masked_out_layer and algos[-1] != 3:
         algos[-1] = 0
     return {'conv_algo': unet.conv_algo,
-            'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1), algos.count(2)],
+            'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1) + algos.count(3), algos.count(2)],
             'executed_mfma_flops': ex, 'executed_tflops': tf, 'frac_executed': tf / peak,
             'algo_note': "achieved / frac count the ALGORITHMIC FLOPs of the convolutions (direct form, SURVEY 8(d)); with "
                          "conv_algo 'winograd' the 3x3 layers execute 16 instead of 36 multiplications per 2x2 outputs and the "

@@ -276,8 +276,9 @@ size_t rnr_packed_weight_floats(const rnr_conv_desc* d);
 int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream);
 
 /* Which algorithm rnr_conv2d* runs for (desc, N, input H, input W): 0 = direct implicit GEMM, 1 = Winograd F(2x2, 3x3),
- * 2 = Winograd F(2x2, 2x2) (16 multiplications per 2 x 2 outputs instead of 36, resp. 9 instead of 16); -1 = bad arguments.
- * Non-zero only with RNR_CONV_WINOGRAD in desc->flags.  Masked launches (tile_mask != NULL) and rnr_conv2d_ray always run 0. */
+ * 3 = the same for the 80-column out layer (16 x 16 x 4 MFMA tiles), 2 = Winograd F(2x2, 2x2) (16 multiplications per 2 x 2
+ * outputs instead of 36, resp. 9 instead of 16); -1 = bad arguments.  Non-zero only with RNR_CONV_WINOGRAD in desc->flags.
+ * Masked launches (tile_mask != NULL) run 0 unless the plan is 3; rnr_conv2d_ray always runs 0. */
 int rnr_conv_algorithm(const rnr_conv_desc* d, int num_views, int in_h, int in_w);
 
 /* Scratch bytes rnr_conv2d may need for (desc, N, input H, input W) (split-K partial slabs). */

@@ -1709,26 +1709,28 @@ pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __res
 }
 
 #include "conv_wino.inc"
+#include "conv_wino80.inc"
 #include "conv_wino2.inc"
 
-// mask[tile] = any(alpha > 0) over the 32 x th output pixels of the tile (tile order = the halo kernels' mt index)
+// mask[tile] = any(alpha > 0) over the tw x th output pixels of the tile (tile order = the halo kernels' mt index)
 __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restrict__ alpha, uint8_t* __restrict__ mask, int H,
-                                                          int W, int th) {
-    const int tiles_x = W / 32, tiles_y = H / th;
+                                                          int W, int th, int tw) {
+    const int tiles_x = W / tw, tiles_y = H / th;
     const int mt = blockIdx.x;
     const int n = mt / (tiles_x * tiles_y);
     const int trem = mt - n * (tiles_x * tiles_y);
-    const int y0 = (trem / tiles_x) * th, x0 = (trem % tiles_x) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int y0 = (trem / tiles_x) * th, x0 = (trem % tiles_x) * tw;
+    const int tx = threadIdx.x % tw, ty = threadIdx.x / tw;
     int any = 0;
-    for (int y = ty; y < th; y += 8) any |= alpha[((size_t)n * H + y0 + y) * W + x0 + tx] > 0.f ? 1 : 0;
+    for (int y = ty; y < th; y += 256 / tw) any |= alpha[((size_t)n * H + y0 + y) * W + x0 + tx] > 0.f ? 1 : 0;
     any = __syncthreads_or(any);
     if (threadIdx.x == 0) mask[mt] = any ? 1 : 0;
 }
 
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
-    int wino;       // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 8 pixel tiles x 64 columns), 2: conv_wino2_kernel (F(2x2, 2x2),
+    int wino;       // 3: conv_wino80_kernel (F(2x2, 3x3) for the 80-column out layer, 16 x 4 pixel tiles),
+                    // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 8 pixel tiles x 64 columns), 2: conv_wino2_kernel (F(2x2, 2x2),
                     // the 4x4 stride-2 convolutions: 16 x 8 tiles of the GEMM row space x 128 (conv) / 64 (transposed) columns)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
     int bm, bn, mtiles, ntiles, par, splitk;
@@ -1873,6 +1875,17 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
             p->splitk = 1;
         }
     }
+    // ... and the 80-column out layer on the 16 x 16 x 4 instruction: 16 x 4 pixel tiles x all 80 columns (conv_wino80_kernel)
+    if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && d->c_out_pad == 80 && H % W80_PH == 0 &&
+        W % W80_PW == 0 && view_elems < (1L << 30)) {
+        const long wgs = (long)N * (H / W80_PH) * (W / W80_PW);
+        if (wgs >= min_wgs) {
+            p->wino = 3; p->halo = 1; p->cfg = 1; p->tw = W80_PW; p->bm = W80_PW * W80_PH; p->bn = 80;
+            p->mtiles = N * (H / W80_PH) * (W / W80_PW);
+            p->ntiles = 1;
+            p->splitk = 1;
+        }
+    }
     // Winograd F(2x2, 2x2) for the 4x4 stride-2 convolutions: 16 x 16 output pixels x 128 columns (convolution) or the four
     // parity classes of 16 x 8 input pixels x 64 columns (transposed) per workgroup
     if ((d->flags & RNR_CONV_WINOGRAD) && d->kind != RNR_CONV3x3_REFLECT && p->Wo % WINO_PW == 0 &&
@@ -1961,6 +1974,7 @@ using namespace rnr;
 static size_t wino_weight_floats(const rnr_conv_desc* d) {       // 0: this convolution has no Winograd image
     if (!(d->flags & RNR_CONV_WINOGRAD)) return 0;
     const size_t npairs = (size_t)(d->c_in0_pad + d->c_in1_pad) / 2;       // K steps per tap set
+    if (d->kind == RNR_CONV3x3_REFLECT && d->c_out_pad == 80) return (npairs / 2 + W80_BDIST) * W80_STEP_FLOATS;
     if (d->kind == RNR_CONV3x3_REFLECT)
         return d->c_out_pad % WINO_BN ? 0 : (size_t)(d->c_out_pad / WINO_BN) * (npairs + WINO_BDIST) * WINO_STEP_FLOATS;
     if (d->kind == RNR_CONVT4x4S2)
@@ -2007,7 +2021,10 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
     }
     if (wino_weight_floats(d)) {
         const long nw = (long)wino_weight_floats(d);
-        if (d->kind == RNR_CONV3x3_REFLECT)
+        if (d->kind == RNR_CONV3x3_REFLECT && d->c_out_pad == 80)
+            hipLaunchKernelGGL(pack_weight_wino80_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
+                               weight, packed + total, nw);
+        else if (d->kind == RNR_CONV3x3_REFLECT)
             hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
                                weight, packed + total, nw);
         else
@@ -2072,7 +2089,7 @@ extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int
     if (!d || num_views <= 0 || d->kind != RNR_CONV3x3_REFLECT) return 0;
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
-    return (pl.halo && !pl.wino && pl.tw == 32 && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
+    return (pl.halo && (pl.wino == 3 || (!pl.wino && pl.tw == 32)) && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
 }
 
 extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha, uint8_t* tile_mask, int num_views,
@@ -2084,7 +2101,7 @@ extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha,
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
     hipLaunchKernelGGL(active_tile_kernel, dim3((unsigned)pl.mtiles), dim3(256), 0, as_stream(stream), alpha, tile_mask,
-                       in_h, in_w, pl.bm / 32);
+                       in_h, in_w, pl.bm / pl.tw, pl.tw);
     return check_launch("active_tile_kernel");
 }
 
@@ -2111,7 +2128,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     hipStream_t st = as_stream(stream);
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
-    if (pl.wino && (tile_mask || g_ray.w)) {    // masked / ray-epilogue launches run on the direct kernels' tiles
+    if (pl.wino && (g_ray.w || (tile_mask && pl.wino != 3))) {    // ray-epilogue / masked launches run on the direct kernels' tiles (the out layer's own Winograd kernel takes a mask)
         rnr_conv_desc dd = *d;
         dd.flags &= ~RNR_CONV_WINOGRAD;
         make_plan(&dd, num_views, in_h, in_w, &pl);
@@ -2213,6 +2230,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
         P.weight_wino = weight_packed + packed_f32_floats(d);
         P.par_inner = 0;
         if (pl.wino == 1) launch_wino(dim3((unsigned)grid_wgs), P, st);
+        else if (pl.wino == 3) launch_wino80(dim3((unsigned)grid_wgs), P, st);
         else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
         else launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);
     }
@@ -2258,7 +2276,9 @@ extern "C" int rnr_conv2d_ray(const rnr_conv_desc* d, const rnr_conv_src* src0, 
     RNR_REQUIRE(ray_w && bias && image, "rnr_conv2d_ray: null pointer argument");
     if (int e = check_desc(d, "rnr_conv2d_ray")) return e;
     ConvPlan pl;
-    make_plan(d, num_views, in_h, in_w, &pl);
+    rnr_conv_desc dd = *d;
+    dd.flags &= ~RNR_CONV_WINOGRAD;         // the ray-renderer epilogue lives in the direct 80-column kernel
+    make_plan(&dd, num_views, in_h, in_w, &pl);
     RNR_REQUIRE(d->kind == RNR_CONV3x3_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && pl.cfg == 1 && pl.tw == 32 &&
                     d->c_out % 3 == 0 && d->c_out_pad == 80,
                 "rnr_conv2d_ray: only the exact-fp32 3x3 out layer on the 80-column plan (65 <= c_out <= 80, c_out = 3 x rays, map "

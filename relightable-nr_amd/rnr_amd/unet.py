@@ -195,9 +195,9 @@ class UNetPlan:
         for i, s in enumerate(self.steps):
             d, (h, w) = s['desc'], s['in_hw']
             algo = self.L.rnr_conv_algorithm(ctypes.byref(d), int(n_views), h, w)
-            if masked_out_layer and i == len(self.steps) - 1:
+            if masked_out_layer and i == len(self.steps) - 1 and algo != 3:
                 algo = 0
-            total += self._layer_flops(d, h, w) / {0: 1.0, 1: 36.0 / 16.0, 2: 16.0 / 9.0}[algo]
+            total += self._layer_flops(d, h, w) / {0: 1.0, 1: 36.0 / 16.0, 2: 16.0 / 9.0, 3: 36.0 / 16.0}[algo]
         return total
 
     @staticmethod
@@ -249,14 +249,21 @@ class UNetPlan:
         L, st = self.L, _stream()
         last = self.steps[-1]
         mask = None
+        # the ray-renderer epilogue lives in the direct 80-column kernel: that call (and its tile mask) use the out layer's
+        # descriptor without the Winograd flag (same packed buffer: the direct image comes first)
+        out_desc = last['desc']
+        if ray is not None and (out_desc.flags & _lib.CONV_WINOGRAD):
+            out_desc = RnrConvDesc(out_desc.kind, out_desc.c_in0, out_desc.c_in0_pad, out_desc.c_in1, out_desc.c_in1_pad,
+                                   out_desc.c_out, out_desc.c_out_pad, out_desc.flags & ~_lib.CONV_WINOGRAD)
+        self._out_desc = out_desc
         if consumer_alpha is not None:
             h, w = last['in_hw']
-            tiles = L.rnr_conv_tile_count(ctypes.byref(last['desc']), n, h, w)
+            tiles = L.rnr_conv_tile_count(ctypes.byref(out_desc), n, h, w)
             if tiles and last['bn'] is None:
                 if self._tile_mask is None or self._tile_mask.numel() < tiles:
                     self._tile_mask = torch.empty(tiles, dtype=torch.uint8, device=self.dev)
                 mask = self._tile_mask
-                check(L.rnr_conv_active_tiles(ctypes.byref(last['desc']), _ptr(consumer_alpha), _ptr(mask), n, h, w, st))
+                check(L.rnr_conv_active_tiles(ctypes.byref(out_desc), _ptr(consumer_alpha), _ptr(mask), n, h, w, st))
         try:
             self._run_steps(n, mask, L, st, ray)
         except Exception:
@@ -282,7 +289,7 @@ class UNetPlan:
             h, w = s['in_hw']
             if s is last and ray is not None:
                 ray_w, image = ray
-                check(L.rnr_conv2d_ray(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
+                check(L.rnr_conv2d_ray(ctypes.byref(self._out_desc), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
                                        _ptr(s['packed']), _ptr(ray_w), _ptr(self.out_bias), _ptr(image), n, h, w,
                                        _ptr(mask), st))
                 continue

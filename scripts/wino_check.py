@@ -52,7 +52,7 @@ def main():
     torch.manual_seed(1)
     V = a.views
     for kind, H, cins, cout in [(0, 64, (64,), 64), (0, 128, (108,), 64), (0, 64, (128,), 128), (0, 32, (256,), 256),
-                                (0, 32, (512,), 512), (0, 64, (64, 64), 64), (0, 16, (512,), 512), (0, 48, (32,), 192),
+                                (0, 32, (512,), 512), (0, 64, (64, 64), 64), (0, 128, (64, 64), 78), (0, 64, (112,), 78), (0, 16, (512,), 512), (0, 48, (32,), 192),
                                 (2, 16, (512,), 512), (2, 32, (64, 64), 64), (2, 64, (128, 128), 64), (2, 32, (256, 256), 128),
                                 (2, 16, (48,), 192), (1, 64, (64,), 128), (1, 128, (128,), 256), (1, 32, (512,), 512),
                                 (1, 96, (32,), 128)]:

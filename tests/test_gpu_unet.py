@@ -244,14 +244,18 @@ def test_conv_vs_torch(kind, N, H, W, cins, c_out):
 
 
 WINO_CASES = [
-    # kind, N, H, W, [C per source], c_out, algorithm rnr_conv_algorithm must report (0 direct, 1 F(2x2,3x3), 2 F(2x2,2x2));
+    # kind, N, H, W, [C per source], c_out, algorithm rnr_conv_algorithm must report (0 direct, 1 F(2x2,3x3), 2 F(2x2,2x2),
+    # 3 F(2x2,3x3) on the 80-column out layer);
     # the Winograd plans need >= 256 (3x3) / >= 200 (4x4 stride 2) workgroups
     (0, 2, 64, 128, [64], 128, 1),      # 3x3: two column tiles, 8 x 8 pixel tiles per view, reflection on all four borders
     (0, 2, 128, 128, [108], 64, 1),     # the input layer's channel count (7 chunks, 4 padding channels), one column tile
     (0, 16, 32, 32, [64, 64], 128, 1),  # skip concat (two sources with their own scale / shift / activation), 16 views
     (0, 9, 8, 16, [256], 256, 0),       # too few tiles (36 workgroups): the direct kernels
     (0, 64, 8, 16, [256], 256, 1),      # map = exactly one 16 x 8 tile per view: every halo pixel reflected
-    (0, 2, 128, 128, [64, 64], 78, 0),  # the out layer's 78 columns: not a multiple of 64 -> direct kernels from the same buffer
+    (0, 2, 128, 128, [64, 64], 78, 3),  # the out layer's 78 columns: conv_wino80_kernel (16 x 16 x 4 MFMA, five column blocks)
+    (0, 4, 64, 64, [112], 78, 3),       # ... 7 chunks, four 64 x 64 maps: exactly 256 workgroups
+    (0, 1, 32, 64, [64], 78, 0),        # ... too few tiles: the direct 80-column plan
+    (0, 4, 64, 64, [64], 72, 3),        # 72 live columns in the 80-column kernel: the padding columns stay zero
     (2, 2, 64, 64, [128], 256, 2),      # transposed: four parity classes on one staged halo, zero border, four column tiles
     (2, 16, 16, 16, [512], 512, 2),     # layer 12 at 16 views: 2 tiles per view, 32 chunks
     (2, 16, 32, 64, [64, 64], 64, 2),   # skip concat, non-square, one column tile
@@ -332,7 +336,7 @@ def test_unet_plan_winograd_vs_direct():
     direct = UNetPlan(sd, 30, 78, 64, 5, (256, 256), 8, dev, conv_algo='direct')
     assert wino.conv_algo == 'winograd' and direct.conv_algo == 'direct'
     algos = [wino.L.rnr_conv_algorithm(ctypes.byref(s['desc']), 8, *s['in_hw']) for s in wino.steps]
-    assert algos.count(1) >= 8 and algos.count(2) >= 3 and algos[-1] == 0, algos
+    assert algos.count(1) >= 8 and algos.count(2) >= 3 and algos[-1] == 3, algos
     assert all(direct.L.rnr_conv_algorithm(ctypes.byref(s['desc']), 8, *s['in_hw']) == 0 for s in direct.steps)
     assert wino.mfma_flops_per_view(8) < 0.75 * wino.flops_per_view and direct.mfma_flops_per_view(8) == direct.flops_per_view
     x = torch.randn(8, 256, 256, wino.in_c_pad, generator=torch.Generator().manual_seed(1)).to(dev)
