@@ -204,6 +204,10 @@ def pmc_traffic_per_step(args, views_per_step=None):
                     'precision': 'bf16x6' if 'bf16x6' in os.path.basename(f) else 'f32', 'img_size': 512}
         if (meta['views_per_step'], meta['precision'], meta.get('img_size', 512)) != (V, args.precision, args.img_size):
             continue
+        # profiles recorded before the Winograd kernels existed carry no conv_algo: they are the direct path's
+        algo = (args.conv_algo or 'winograd') if args.precision == 'f32' else 'direct'
+        if meta.get('conv_algo', 'direct') != algo:
+            continue
         steps = meta['steps'] + meta['warmup']
         kb = sum(2.0 * v.get('FETCH_SIZE_total', 0.0) + v.get('WRITE_SIZE_total', 0.0)
                  for k, v in prof.items() if k.startswith('conv_') or 'conv_' in k.split('(')[0])

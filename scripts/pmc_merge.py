@@ -23,6 +23,6 @@ for k, v in acc.items():
 # how the passes were run (scripts/pmc.sh exports these): bench.py refuses to scale a profile to another batch size
 res['_meta'] = {'views_per_step': int(os.environ.get('VIEWS', '4')), 'steps': int(os.environ.get('PMC_STEPS', '2')),
                 'warmup': int(os.environ.get('PMC_WARMUP', '1')), 'precision': os.environ.get('PRECISION', 'f32'),
-                'img_size': int(os.environ.get('IMG', '512'))}
+                'img_size': int(os.environ.get('IMG', '512')), 'conv_algo': os.environ.get('CONV_ALGO', 'winograd')}
 json.dump(res, open(os.path.join(out, 'merged.json'), 'w'), indent=1, sort_keys=True)
 print('kernels', len(res))

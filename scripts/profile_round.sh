@@ -1,39 +1,43 @@
 #!/bin/bash
 # usage (GPU box, from the repo root): scripts/profile_round.sh TAG      e.g. TAG=r03
 # Collects everything profiles/ holds for a round into gpurun_out/profile_TAG/:
-#   kernel-trace statistics of the bench loop (8 views per step: three conv precisions; 1 view per step = the reference's
-#   calling mode: exact fp32), the PMC passes (separate runs per counter group, never combined with other trace domains) at
-#   both batch sizes, per-layer timing tables, the per-layer accuracy table of the emulation kernels, and the bench line
+#   kernel-trace statistics of the bench loop (8 views per step and 1 view per step = the reference's calling mode, product path =
+#   Winograd convolutions; 8 views per step with direct convolutions and with the two emulated precisions), the PMC passes
+#   (separate runs per counter group, never combined with other trace domains) of the product path at both batch sizes,
+#   per-layer timing tables (both algorithms), the accuracy tables of the Winograd and emulation kernels, and the bench line
 #   itself (roofline.traffic taken from THIS run's PMC files, for the headline and for single_view_mode).
 TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-for cfg in f32:8 f32:1 f16x3:8 bf16x6:8; do
-  prec=${cfg%%:*}; v=${cfg##*:}
+for cfg in f32:8:winograd f32:1:winograd f32:8:direct f16x3:8:direct bf16x6:8:direct; do
+  prec=${cfg%%:*}; rest=${cfg#*:}; v=${rest%%:*}; algo=${rest##*:}
+  name=$prec; [ $prec = f32 ] && [ $algo = direct ] && name=f32_direct
   steps=5; [ $v = 1 ] && steps=20
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_${prec}_$v -- python $ROOT/bench.py --steps $steps --warmup 2 \
-      --views-per-step $v --no-cpu-baseline --main-loop-only --precision $prec > $OUT/kt_${prec}_$v.log 2>&1
-  find $OUT/kt_${prec}_$v -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats_${prec}_steps${steps}_views$v.csv
-  [ $v = 1 ] && find $OUT/kt_${prec}_$v -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_trace_views1.csv
-  tail -1 $OUT/kt_${prec}_$v.log > $OUT/${TAG}_bench_line_under_profiler_${prec}_views$v.json
-  rm -rf $OUT/kt_${prec}_$v
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_${name}_$v -- python $ROOT/bench.py --steps $steps --warmup 2 \
+      --views-per-step $v --no-cpu-baseline --main-loop-only --precision $prec --conv-algo $algo > $OUT/kt_${name}_$v.log 2>&1
+  find $OUT/kt_${name}_$v -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats_${name}_steps${steps}_views$v.csv
+  [ $v = 1 ] && find $OUT/kt_${name}_$v -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_trace_views1.csv
+  tail -1 $OUT/kt_${name}_$v.log > $OUT/${TAG}_bench_line_under_profiler_${name}_views$v.json
+  rm -rf $OUT/kt_${name}_$v
 done
 cd $ROOT
 python scripts/trace_frame.py $OUT/kernel_trace_views1.csv > $OUT/${TAG}_frame_timeline_f32_views1.txt 2>&1
 rm -f $OUT/kernel_trace_views1.csv
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
-for cfg in f32:8 f32:1 f16x3:8 bf16x6:8; do
-  prec=${cfg%%:*}; v=${cfg##*:}
-  PRECISION=$prec VIEWS=$v scripts/pmc.sh ${TAG}_${prec}_$v "FETCH_SIZE" "WRITE_SIZE" "$SQ1" "$SQ2" "TCC_HIT_sum TCC_MISS_sum" > $OUT/pmc_${prec}_$v.log 2>&1
-  cp gpurun_out/pmc_${TAG}_${prec}_$v/merged.json $OUT/${TAG}_pmc_per_kernel_${prec}_steps2_views$v.json
+for v in 8 1; do
+  CONV_ALGO=winograd PRECISION=f32 VIEWS=$v scripts/pmc.sh ${TAG}_f32_$v "FETCH_SIZE" "WRITE_SIZE" "$SQ1" "$SQ2" "TCC_HIT_sum TCC_MISS_sum" > $OUT/pmc_f32_$v.log 2>&1
+  cp gpurun_out/pmc_${TAG}_f32_$v/merged.json $OUT/${TAG}_pmc_per_kernel_f32_steps2_views$v.json
 done
 # bench.py takes single_view_mode's roofline.traffic from the newest committed views-1 profile: make this run's the newest
 cp $OUT/${TAG}_pmc_per_kernel_f32_steps2_views1.json $ROOT/profiles/
-for v in 1 2 4 8; do python scripts/layer_time.py --views $v > $OUT/${TAG}_layer_time_f32_views$v.txt 2>&1; done
-python scripts/emu_layer_table.py > $OUT/${TAG}_emu_layer_table.md 2> $OUT/emu_layer_table.err
-python bench.py --pmc-file $OUT/${TAG}_pmc_per_kernel_f32_steps2_views8.json > $OUT/bench.log 2>&1
+for v in 1 8; do
+  timeout 300 python scripts/layer_time.py --views $v --winograd > $OUT/${TAG}_layer_time_f32_views$v.txt 2>&1
+  timeout 300 python scripts/layer_time.py --views $v > $OUT/${TAG}_layer_time_f32_direct_views$v.txt 2>&1
+done
+RNR_WINO_MIN_WGS=1 RNR_WINO2_MIN_WGS=1 timeout 600 python scripts/wino_check.py --views 2 > $OUT/${TAG}_winograd_accuracy.txt 2>&1
+timeout 900 python bench.py --pmc-file $OUT/${TAG}_pmc_per_kernel_f32_steps2_views8.json > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/${TAG}_bench_final.json
 ls -la $OUT
