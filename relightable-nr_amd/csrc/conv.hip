@@ -1744,12 +1744,30 @@ __global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, l
     if (i < n) p[i] = 0.0;
 }
 
+#ifndef RNR_WINO_SPLIT_MIN_CHUNKS
+#define RNR_WINO_SPLIT_MIN_CHUNKS 4     // 16-channel chunks per split-K slice of a Winograd kernel, at least
+#define RNR_WINO_SPLIT_MIN_WGS 192      // workgroups a split Winograd grid must reach (128: the 64^2 stride-2 and 16^2 transposed layers at one view lose 7 - 14 us)
+#endif
 #ifndef RNR_WINO2_MIN_WGS
 #define RNR_WINO2_MIN_WGS 200        // fewer workgroups (one per CU) than this: the direct kernels
 #endif
 #ifndef RNR_WINO_MIN_WGS
 #define RNR_WINO_MIN_WGS 256         // fewer 16 x 8 pixel x 64 column tiles than this: the direct kernels (they split K)
 #endif
+
+// split depth of a Winograd grid of `wgs` workgroups (0: too small even when split — the direct kernels).  Below `min_wgs`
+// the K loop is cut into slices whose partial outputs splitk_reduce_kernel adds: at least 4 chunks per slice, at most 8
+// slices, and the split grid must reach half of `min_wgs`.  RNR_WINO_SPLITK=0 in the environment disables the split.
+static int wino_splitk(long wgs, int min_wgs, int chunks) {
+    if (wgs >= min_wgs) return 1;
+    static const int enabled = [] { const char* e = getenv("RNR_WINO_SPLITK"); return e ? atoi(e) : 1; }();
+    if (!enabled || wgs <= 0) return 0;
+    int sk = (int)((min_wgs + wgs - 1) / wgs);
+    const int max_sk = chunks / RNR_WINO_SPLIT_MIN_CHUNKS < 8 ? chunks / RNR_WINO_SPLIT_MIN_CHUNKS : 8;
+    if (sk > max_sk) sk = max_sk;
+    if (sk < 2 || wgs * sk < RNR_WINO_SPLIT_MIN_WGS) return 0;
+    return sk;
+}
 
 static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     p->wino = 0;
@@ -1868,11 +1886,12 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && H % WINO_PH == 0 && W % WINO_PW == 0 &&
         d->c_out_pad % WINO_BN == 0 && view_elems < (1L << 30)) {
         const long wgs = (long)N * (H / WINO_PH) * (W / WINO_PW) * (d->c_out_pad / WINO_BN);
-        if (wgs >= min_wgs) {
+        const int sk = wino_splitk(wgs, min_wgs, p->chunks_per_tap);
+        if (sk > 0) {
             p->wino = 1; p->halo = 1; p->cfg = 0; p->tw = WINO_PW; p->bm = WINO_PW * WINO_PH; p->bn = WINO_BN;
             p->mtiles = N * (H / WINO_PH) * (W / WINO_PW);
             p->ntiles = d->c_out_pad / WINO_BN;
-            p->splitk = 1;
+            p->splitk = sk;
         }
     }
     // ... and the 80-column out layer on the 16 x 16 x 4 instruction: 16 x 4 pixel tiles x all 80 columns (conv_wino80_kernel)
@@ -1894,12 +1913,13 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
         const int bnw = d->kind == RNR_CONVT4x4S2 ? 64 : 128, tph = d->kind == RNR_CONVT4x4S2 ? WINO_PH : 16;
         const long wgs = (long)N * (p->Ho / tph) * (p->Wo / WINO_PW) * (d->c_out_pad / bnw);
         static const int min_wgs2 = [] { const char* e = getenv("RNR_WINO2_MIN_WGS"); return e ? atoi(e) : RNR_WINO2_MIN_WGS; }();
-        if (wgs >= min_wgs2) {
+        const int sk = wino_splitk(wgs, min_wgs2, p->chunks_per_tap);
+        if (sk > 0) {
             p->wino = 2; p->halo = 1; p->cfg = 0; p->tw = WINO_PW; p->bm = WINO_PW * tph; p->bn = bnw;
             p->mtiles = N * (p->Ho / tph) * (p->Wo / WINO_PW);
             p->ntiles = d->c_out_pad / bnw;
             p->par = 1;
-            p->splitk = 1;
+            p->splitk = sk;
         }
     }
     return 0;
@@ -2038,7 +2058,7 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
 // split-K slices of a tile meet inside the launch (splitk_combine) when there are few of them: the last slice reads
 // splitk accumulator images, a serial tail that a chip-wide reduce kernel beats for deep splits
 static bool combines_in_launch(const ConvPlan& pl) {
-    return pl.halo && pl.splitk > 1 && pl.cfg != 1 && pl.bm * pl.bn <= 128 * 128 &&
+    return pl.halo && !pl.wino && pl.splitk > 1 && pl.cfg != 1 && pl.bm * pl.bn <= 128 * 128 &&
            (long)pl.splitk * pl.bm * pl.bn * (long)sizeof(float) <= RNR_COMBINE_MAX_BYTES;
 }
 static size_t combine_slab_floats(const ConvPlan& pl) {     // one accumulator image per (slice, tile): bm x bn floats

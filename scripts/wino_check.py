@@ -93,9 +93,12 @@ def main():
         r_d = float((o_d[..., :cout].double() - ref).pow(2).mean().sqrt()) / rms
         r_w = float((o_w[..., :cout].double() - ref).pow(2).mean().sqrt()) / rms
         pad_ok = bool((o_w[..., cout:] == 0).all()) if pad16(cout) > cout else True
-        print('kind %d %4d^2 %-9s -> %3d  V=%d  max err / rms: direct %.2e winograd %.2e   rms err / rms: direct %.2e winograd %.2e   '
+        dsc = _lib.RnrConvDesc(kind, cins[0], pad16(cins[0]), cins[1] if len(cins) > 1 else 0, pad16(cins[1]) if len(cins) > 1 else 0,
+                               cout, pad16(cout), _lib.CONV_WINOGRAD)
+        algo = L.rnr_conv_algorithm(ctypes.byref(dsc), V, H, H)
+        print('algo %d  kind %d %4d^2 %-9s -> %3d  V=%d  max err / rms: direct %.2e winograd %.2e   rms err / rms: direct %.2e winograd %.2e   '
               'scale diff %.1e shift diff %.1e  pad cols zero %s  finite %s' % (
-                  kind, H, '+'.join(map(str, cins)), cout, V, e_d, e_w, r_d, r_w, float((sc_d - sc_w).abs().max()),
+                  algo, kind, H, '+'.join(map(str, cins)), cout, V, e_d, e_w, r_d, r_w, float((sc_d - sc_w).abs().max()),
                   float((sh_d - sh_w).abs().max()), pad_ok, bool(torch.isfinite(o_w).all())))
         sys.stdout.flush()
 

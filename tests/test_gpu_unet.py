@@ -250,7 +250,10 @@ WINO_CASES = [
     (0, 2, 64, 128, [64], 128, 1),      # 3x3: two column tiles, 8 x 8 pixel tiles per view, reflection on all four borders
     (0, 2, 128, 128, [108], 64, 1),     # the input layer's channel count (7 chunks, 4 padding channels), one column tile
     (0, 16, 32, 32, [64, 64], 128, 1),  # skip concat (two sources with their own scale / shift / activation), 16 views
-    (0, 9, 8, 16, [256], 256, 0),       # too few tiles (36 workgroups): the direct kernels
+    (0, 9, 8, 16, [256], 256, 0),       # too few tiles (36 workgroups, 144 when split four ways): the direct kernels
+    (0, 1, 32, 32, [512], 512, 1),      # 64 workgroups: split-K four ways (partial outputs per slice + splitk_reduce_kernel + finalise)
+    (2, 1, 64, 64, [256, 256], 256, 2), # 128 workgroups: the transposed kernel split two ways, skip concat across the slices
+    (1, 1, 256, 256, [128], 256, 2),    # 128 workgroups: the stride-2 kernel split two ways (4 chunks x 4 phases per slice)
     (0, 64, 8, 16, [256], 256, 1),      # map = exactly one 16 x 8 tile per view: every halo pixel reflected
     (0, 2, 128, 128, [64, 64], 78, 3),  # the out layer's 78 columns: conv_wino80_kernel (16 x 16 x 4 MFMA, five column blocks)
     (0, 4, 64, 64, [112], 78, 3),       # ... 7 chunks, four 64 x 64 maps: exactly 256 workgroups
