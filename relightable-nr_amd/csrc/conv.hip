@@ -17,7 +17,9 @@
 //                 one fp64 atomic per channel per workgroup) for the next BatchNorm's batch statistics.
 //
 // Kernels: conv_halo_kernel (LDS-halo tiles, exact fp32: every map whose width is a multiple of 32, or 16), conv_mfma_kernel (tap-by-tap gather:
-// the small maps), conv_halo_emu_kernel (opt-in: fp32 emulated on the 16-bit matrix cores, RNR_CONV_F32_EMU_BF16X6 / _F16X3).
+// the small maps), conv_halo_emu_kernel (opt-in: fp32 emulated on the 16-bit matrix cores, RNR_CONV_F32_EMU_BF16X6 / _F16X3), and — the
+// product path since r03, RNR_CONV_WINOGRAD — the fp32 Winograd kernels of conv_wino.inc (F(2x2, 3x3): conv_wino_kernel),
+// conv_wino80.inc (the 80-column out layer) and conv_wino2.inc (F(2x2, 2x2) for the two 4x4 stride-2 convolutions).
 // make_plan() picks the kernel, the tile shape (256x64, 256x80, 128x128 or 256x128 rows x columns) and the split-K depth.
 #include "rnr_internal.h"
 
@@ -2105,10 +2107,21 @@ extern "C" int rnr_conv_algorithm(const rnr_conv_desc* d, int num_views, int in_
     return pl.wino;
 }
 
+// the plan a MASKED launch runs: the out layer's own Winograd kernel takes a mask, the other Winograd kernels do not — those
+// calls run the direct kernels, on the direct kernels' tiles
+static void mask_plan(const rnr_conv_desc* d, int num_views, int in_h, int in_w, ConvPlan* pl) {
+    make_plan(d, num_views, in_h, in_w, pl);
+    if (pl->wino && pl->wino != 3) {
+        rnr_conv_desc dd = *d;
+        dd.flags &= ~RNR_CONV_WINOGRAD;
+        make_plan(&dd, num_views, in_h, in_w, pl);
+    }
+}
+
 extern "C" size_t rnr_conv_tile_count(const rnr_conv_desc* d, int num_views, int in_h, int in_w) {
     if (!d || num_views <= 0 || d->kind != RNR_CONV3x3_REFLECT) return 0;
     ConvPlan pl;
-    make_plan(d, num_views, in_h, in_w, &pl);
+    mask_plan(d, num_views, in_h, in_w, &pl);
     return (pl.halo && (pl.wino == 3 || (!pl.wino && pl.tw == 32)) && pl.splitk == 1) ? (size_t)pl.mtiles : 0;
 }
 
@@ -2119,7 +2132,7 @@ extern "C" int rnr_conv_active_tiles(const rnr_conv_desc* d, const float* alpha,
     RNR_REQUIRE(rnr_conv_tile_count(d, num_views, in_h, in_w) > 0,
                 "rnr_conv_active_tiles: this convolution does not run on maskable pixel tiles (3x3 halo plan without split-K)");
     ConvPlan pl;
-    make_plan(d, num_views, in_h, in_w, &pl);
+    mask_plan(d, num_views, in_h, in_w, &pl);
     hipLaunchKernelGGL(active_tile_kernel, dim3((unsigned)pl.mtiles), dim3(256), 0, as_stream(stream), alpha, tile_mask,
                        in_h, in_w, pl.bm / pl.tw, pl.tw);
     return check_launch("active_tile_kernel");
