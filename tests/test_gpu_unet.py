@@ -313,6 +313,30 @@ def test_conv_winograd_vs_torch(kind, N, H, W, cins, c_out, algo):
     assert float(scale[:, c_out:].abs().max() if scale.shape[1] > c_out else 0.0) == 0.0
 
 
+@pytest.mark.parametrize('kind,N,H,W,cins,c_out', [(0, 2, 64, 128, [64], 128), (0, 1, 32, 32, [512], 512), (2, 2, 64, 64, [128], 256),
+                                                   (1, 4, 256, 256, [16], 128), (0, 2, 128, 128, [64, 64], 78)])
+def test_conv_winograd_legacy_entry_point_statistics(kind, N, H, W, cins, c_out):
+    """rnr_conv2d (the entry point of bn_mode 'batch_all' and of external callers: statistics into a caller buffer, no
+    BatchNorm finalise, one statistics shard) with RNR_CONV_WINOGRAD, split-K case included: output and per-view
+    sum / sum of squares against float64."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(kind * 77 + H + c_out)
+    srcs = [(torch.randn(N, C, H, W, generator=g), torch.rand(N, C, generator=g) + 0.5, torch.randn(N, C, generator=g) * 0.3,
+             1 if kind != 2 and j == 0 else 2) for j, C in enumerate(cins)]
+    cin = sum(cins)
+    if kind == 2:
+        w = torch.randn(cin, c_out, 4, 4, generator=g) / (cin * 4) ** 0.5
+    else:
+        k = 3 if kind == 0 else 4
+        w = torch.randn(c_out, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    out, stats = run_conv(kind, srcs, w, c_out, N, H, W, flags=_lib.CONV_WINOGRAD)
+    ref = ref_conv(kind, srcs, w).permute(0, 2, 3, 1)
+    assert torch.isfinite(out).all()
+    assert (out[..., :c_out].double() - ref).abs().max() < 3e-5 * ref.abs().max()
+    assert torch.allclose(stats[:, :c_out, 0], ref.sum(dim=(1, 2)), rtol=1e-4, atol=1e-3 * float(ref.abs().max()) * H * W ** 0.5)
+    assert torch.allclose(stats[:, :c_out, 1], (ref * ref).sum(dim=(1, 2)), rtol=1e-4)
+
+
 def test_conv_winograd_is_run_to_run_stable_and_flag_is_checked():
     """out_raw of the Winograd kernels is bit-reproducible run to run (fixed summation order; only the statistics are
     floating-point atomics), and the flag is refused together with an emulation format."""
