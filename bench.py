@@ -526,7 +526,8 @@ def main(argv=None):
                                    '(f32 MFMA convs + SH relight), UV-sphere 65536 faces, neural texture 512^2 x %d ch x 4 '
                                    'levels, U-Net %d->%d nf0=%d' % (V, args.img_size, args.img_size, args.tex_ch, sc['c_in'],
                                                                    3 * sc['n_rays'], args.nf0),
-                       'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world},
+                       'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world,
+                       'conv_algo': None if stub else pipe.unet.conv_algo},
             'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
                          'achieved': achieved_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': achieved_tf / peak_tf, **algo8, 'traffic': traffic,
