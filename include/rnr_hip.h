@@ -266,7 +266,9 @@ typedef struct rnr_conv_desc {
  * direct <= 8.6e-6).  Must be set both when packing the weights (the transformed image is stored behind the direct one) and
  * when convolving; calls it does not cover (maps that do not tile into 16 x 8 / 16 x 16 pixels, column counts that are not
  * multiples of 64 / 128, masked launches, too few tiles to fill the chip: rnr_conv_algorithm tells) run the direct kernels
- * from the same buffer.  Not combined with the emulation flags. */
+ * from the same buffer.  Not combined with the emulation flags.  Non-finite inputs: the data transforms take differences of
+ * neighbouring pixels, so an inf / NaN activation reaches every output of the 2 x 2 tiles whose patch contains it (a direct
+ * convolution confines it to the outputs whose window contains it). */
 #define RNR_CONV_WINOGRAD 8
 
 /* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
