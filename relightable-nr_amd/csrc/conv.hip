@@ -1488,34 +1488,35 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
 #undef RNR_PERSIST_PART
 #endif
 
-// out[m,c] = sum_s slab[s][m,c]; statistics per view.  One float4 of one output row per thread (16 rows x 64 columns
-// per 256-thread workgroup), so even the 16x16 maps spread over >= 128 workgroups.
+// out[m,c] = sum_s slab[s][m,c]; statistics per view.  One float4 of an output row per thread and pass: 16 rows x 64 columns
+// per pass of a 256-thread workgroup, rpw / 16 passes (the host picks rpw = 16 ... 128 rows per workgroup so that big maps do
+// not pay one float64 atomic per 16 rows and column, while even the 16 x 16 maps spread over >= 128 workgroups).
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splitk, float* __restrict__ out,
-                     long rows, int rows_per_view, const ConvParams P) {
-    __shared__ float red[16][64][2];
+                     long rows, int rows_per_view, int rpw, const ConvParams P) {
+    __shared__ double red[16][64][2];
     double* const stats = P.stats;
     const int c_out = P.c_out, c_out_pad = P.c_out_pad;
     const int tid = threadIdx.x;
     const int cq = tid & 15, ry = tid >> 4;
     const int col = blockIdx.y * 64 + cq * 4;
-    const long r0 = (long)blockIdx.x * 16;
-    const long m = r0 + ry;
-    const bool single_view = (r0 / rows_per_view) == ((min(r0 + 16, rows) - 1) / rows_per_view);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool live = m < rows && col < c_out_pad;
-    if (live) {
+    const long r0 = (long)blockIdx.x * rpw;
+    const bool single_view = (r0 / rows_per_view) == ((min(r0 + rpw, rows) - 1) / rows_per_view);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rr = 0; rr < rpw; rr += 16) {
+        const long m = r0 + rr + ry;
+        const bool live = m < rows && col < c_out_pad;
+        if (!live) continue;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* p = slabs + (size_t)m * c_out_pad + col;
         for (int s = 0; s < splitk; s++) {
             const float4 t = *reinterpret_cast<const float4*>(p + (size_t)s * slab_stride);
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         *reinterpret_cast<float4*>(out + (size_t)m * c_out_pad + col) = v;
-    }
-    if (!stats) return;
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-    if (!single_view) {     // rows of two views in one workgroup: maps smaller than 16 pixels
-        if (live) {
+        if (!stats) continue;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if (!single_view) {     // rows of two views in one workgroup (maps smaller than 16 pixels; rpw = 16 there)
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (col + k < c_out) {
@@ -1523,12 +1524,17 @@ splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int spli
                     atomicAdd(st + 0, (double)vv[k]);
                     atomicAdd(st + 1, (double)vv[k] * (double)vv[k]);
                 }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { s1[k] += (double)vv[k]; s2[k] += (double)vv[k] * (double)vv[k]; }
         }
-    } else {
+    }
+    if (!stats) return;
+    if (single_view) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            red[ry][cq * 4 + k][0] = live ? vv[k] : 0.f;
-            red[ry][cq * 4 + k][1] = live ? vv[k] * vv[k] : 0.f;
+            red[ry][cq * 4 + k][0] = s1[k];
+            red[ry][cq * 4 + k][1] = s2[k];
         }
         __syncthreads();
         if (tid < 64) {
@@ -1536,7 +1542,7 @@ splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int spli
             if (c < c_out) {
                 double a = 0.0, b2 = 0.0;
 #pragma unroll
-                for (int r = 0; r < 16; r++) { a += (double)red[r][tid][0]; b2 += (double)red[r][tid][1]; }
+                for (int r = 0; r < 16; r++) { a += red[r][tid][0]; b2 += red[r][tid][1]; }
                 double* st = stat_slot(P, (int)(r0 / rows_per_view), c);
                 atomicAdd(st + 0, a);
                 atomicAdd(st + 1, b2);
@@ -2278,9 +2284,12 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     if (int e = check_launch("conv_mfma_kernel")) return e;
     if (pl.splitk > 1 && !combine) {
         const long rows = (long)num_views * pl.OH * pl.OW;
-        const dim3 grid((unsigned)((rows + 15) / 16), (unsigned)((d->c_out_pad + 63) / 64));
+        const int col_tiles = (d->c_out_pad + 63) / 64, rows_per_view = pl.OH * pl.OW;
+        int rpw = 128;          // rows per workgroup: as many as leave >= 512 workgroups and stay inside one view
+        while (rpw > 16 && (rows_per_view % rpw != 0 || (rows / rpw) * col_tiles < 512)) rpw >>= 1;
+        const dim3 grid((unsigned)((rows + rpw - 1) / rpw), (unsigned)col_tiles);
         hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, reinterpret_cast<const float*>(workspace),
-                           (long)out_floats, pl.splitk, out_raw, rows, pl.OH * pl.OW, P);
+                           (long)out_floats, pl.splitk, out_raw, rows, rows_per_view, rpw, P);
         if (int e = check_launch("splitk_reduce_kernel")) return e;
     }
     if (with_bn && !in_kernel_bn) {
