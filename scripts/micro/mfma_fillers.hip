@@ -8,7 +8,7 @@
 #include <stdio.h>
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-// KIND 0: VALU fillers, 1: LDS reads, 2: global loads (L2-resident)
+// KIND 0: VALU fillers, 1: LDS reads (b64), 2: global loads (dwordx4, L2-resident), 3: global loads (dword), 4: LDS reads (b128)
 template <int F, int KIND>
 __global__ void __launch_bounds__(256) spin(const float* __restrict__ src, float* __restrict__ sink, int iters) {
     __shared__ float lds[4096];
@@ -32,10 +32,12 @@ __global__ void __launch_bounds__(256) spin(const float* __restrict__ src, float
             for (int k = 0; k < F; k++) {
                 if (KIND == 0) f[(c + k) & 7] = __builtin_fmaf(f[(c + k) & 7], 1.0001f, 0.5f);
                 else if (KIND == 1) { typedef float f2 __attribute__((ext_vector_type(2))); const f2 v = *reinterpret_cast<const f2*>(lp + 8 * ((c + k + it) & 7)); f[(c + k) & 7] += v.x; }
-                else { const f4 v = gp[64 * ((c * F + k + it) & 15)]; g4.x += v.x; }
+                else if (KIND == 2) { const f4 v = gp[64 * ((c * F + k + it) & 15)]; g4.x += v.x; }
+                else if (KIND == 3) { g4.x += src[(tid & 63) + 64 * ((c * F + k + it) & 63)]; }
+                else { const f4 v = *reinterpret_cast<const f4*>(lds + 4 * (tid & 255) + 1024 * ((c + k + it) & 3)); f[(c + k) & 7] += v.x; }
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (F > 0) __builtin_amdgcn_sched_group_barrier(KIND == 0 ? 0x002 : (KIND == 1 ? 0x100 : 0x020), F, 0);
+            if (F > 0) __builtin_amdgcn_sched_group_barrier(KIND == 0 ? 0x002 : ((KIND == 1 || KIND == 4) ? 0x100 : 0x020), F, 0);
             if (F > 0 && KIND != 0) __builtin_amdgcn_sched_group_barrier(0x002, F, 0);
         }
     }
@@ -61,7 +63,7 @@ static void run(const float* src, float* sink, int waves_per_simd, double mhz) {
     const double mfma_per_simd = (double)iters * 8 * waves_per_simd;
     const double cyc = ms * 1e-3 * mhz * 1e6 / mfma_per_simd;
     printf("  {\"kind\": \"%s\", \"fillers_per_mfma\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"pipe_cycles_per_mfma_at_%.0f_MHz\": %.1f, \"tflops\": %.1f},\n",
-           KIND == 0 ? "valu" : (KIND == 1 ? "lds" : "vmem"), F, waves_per_simd, ms, mhz, cyc,
+           KIND == 0 ? "valu" : (KIND == 1 ? "lds_b64" : (KIND == 2 ? "vmem_dwordx4" : (KIND == 3 ? "vmem_dword" : "lds_b128"))), F, waves_per_simd, ms, mhz, cyc,
            mfma_per_simd * 1024.0 * 4096.0 / (ms * 1e-3) / 1e12);
 }
 
@@ -80,6 +82,8 @@ int main() {
         run<2, 0>(src, sink, w, mhz); run<4, 0>(src, sink, w, mhz); run<8, 0>(src, sink, w, mhz); run<12, 0>(src, sink, w, mhz);
         run<1, 1>(src, sink, w, mhz); run<2, 1>(src, sink, w, mhz);
         run<1, 2>(src, sink, w, mhz); run<2, 2>(src, sink, w, mhz);
+        run<1, 3>(src, sink, w, mhz); run<2, 3>(src, sink, w, mhz);
+        run<1, 4>(src, sink, w, mhz); run<2, 4>(src, sink, w, mhz);
     }
     printf("  {}\n]}\n");
     return 0;
