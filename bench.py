@@ -11,6 +11,9 @@ Single GPU:  python bench.py [--steps K --warmup W]
 N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
              bench.py --gpus N --steps K --warmup W       (weak scaling: every rank renders its own pose slice and the
              frames are all-gathered over RCCL each step — the only collective of the path)
+         or  python bench.py --gpus N ...                 (no launcher: this file starts the N ranks itself, launch_ranks)
+Either way the ranks that took part are counted through the process group (`n_ranks_seen`) and a count other than --gpus is
+an error exit, never a bench line.
 """
 import argparse
 import ctypes
@@ -213,7 +216,7 @@ def pmc_traffic_per_step(args, views_per_step=None):
                  for k, v in prof.items() if k.startswith('conv_') or 'conv_' in k.split('(')[0])
         if kb <= 0:
             continue
-        return kb * 1024.0 / steps, {'traffic_source': os.path.basename(f),
+        return kb * 1024.0 / steps, {'traffic_source': os.path.basename(f), 'traffic_path': os.path.abspath(f),
                                      'traffic_from_committed_profile': not own,
                                      'traffic_profile': meta}
     return None, {'traffic_source': None, 'traffic_from_committed_profile': False,
@@ -266,20 +269,53 @@ def sustained_block(precision, achieved_tf):
                 src, ins, rates[ins], '' if products == 1 else ' (/ %d partial products)' % products)}
 
 
-def algo_block(unet, n_views, stage_ms, peak, masked_out_layer):
-    """What the matrix cores execute beside the algorithmic (direct-form) figure of a roofline block."""
+def pmc_mfma_flops_per_step(info):
+    """Executed MFMA FLOPs per step counted by the hardware: SUM SQ_INSTS_MFMA x FLOPs per wave instruction (4096 for
+    v_mfma_f32_32x32x2_f32, 2048 for the out layer's v_mfma_f32_16x16x4_f32 kernel) over the conv kernels of the SAME PMC
+    file roofline.traffic comes from, / (steps + warm-up) of that profile run.  None without such a file / counter."""
+    path = info.get('traffic_path')
+    if not path:
+        return None
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    meta = info.get('traffic_profile') or prof.get('_meta') or {}
+    steps = meta.get('steps', 2) + meta.get('warmup', 1)
+    tot = 0.0
+    for k, v in prof.items():
+        if k == '_meta' or 'SQ_INSTS_MFMA_total' not in v:
+            continue
+        tot += v['SQ_INSTS_MFMA_total'] * (2048.0 if 'conv_wino80' in k else 4096.0)
+    return tot / steps if tot > 0 else None
+
+
+def algo_block(unet, n_views, stage_ms, peak, masked_out_layer, direct_tf=None, traffic_info=None):
+    """The MFMA roofline of a U-Net stage: `achieved` / `frac` count what the matrix cores EXECUTE (so frac <= 1 by construction);
+    the direct-form (SURVEY 8(d) algorithmic) figure the Winograd kernels replace is reported beside it, never as frac."""
     ex = unet.mfma_flops_per_view(n_views, masked_out_layer) * n_views
     tf = ex / (stage_ms * 1e-3) / 1e12
     algos = [unet.L.rnr_conv_algorithm(ctypes.byref(s['desc']), n_views, *s['in_hw']) for s in unet.steps]
     if masked_out_layer and algos[-1] != 3:
         algos[-1] = 0
-    return {'conv_algo': unet.conv_algo,
-            'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1) + algos.count(3), algos.count(2)],
-            'executed_mfma_flops': ex, 'executed_tflops': tf, 'frac_executed': tf / peak,
-            'algo_note': "achieved / frac count the ALGORITHMIC FLOPs of the convolutions (direct form, SURVEY 8(d)); with "
-                         "conv_algo 'winograd' the 3x3 layers execute 16 instead of 36 multiplications per 2x2 outputs and the "
-                         "4x4 stride-2 ones 9 instead of 16 (fp32 operands, fp32 accumulation, same MFMA instruction), so frac "
-                         "can exceed 1; executed_tflops / frac_executed = what the matrix cores actually run against the same peak"}
+    blk = {'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+           'conv_algo': unet.conv_algo,
+           'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1) + algos.count(3), algos.count(2)],
+           'executed_mfma_flops': ex}
+    pmc = pmc_mfma_flops_per_step(traffic_info or {})
+    blk['executed_flops_from_pmc'] = pmc
+    if pmc:
+        blk['executed_flops_pmc_over_model'] = pmc / ex
+    if direct_tf is not None:
+        blk['effective_tflops_direct_form'] = direct_tf
+        blk['algorithmic_speedup'] = direct_tf / tf
+    blk['algo_note'] = ("achieved / frac = multiply-add FLOPs the matrix cores execute (padding columns / channels included: what "
+                        "SQ_INSTS_MFMA counts, cross-checked by executed_flops_from_pmc = SUM SQ_INSTS_MFMA x 4096 | 2048 of the PMC "
+                        "file named in traffic_source) / stage time / peak.  effective_tflops_direct_form = the ALGORITHMIC FLOPs of "
+                        "SURVEY 8(d) (direct-form convolutions) / the same time: with conv_algo 'winograd' the 3x3 layers execute 16 "
+                        "instead of 36 multiplications per 2x2 outputs and the 4x4 stride-2 / transposed ones 9 instead of 16 (fp32 "
+                        "operands, fp32 accumulation, same MFMA instruction), algorithmic_speedup = their ratio")
+    return blk
 
 
 def make_pipeline(sc, args, dev, V, **kw):
@@ -350,7 +386,10 @@ def single_view_block(sc, args, dev):
     dt_fly = (time.perf_counter() - t0) / n1
     same = float((hs.image - seq_last).abs().max())
     flops_view = pipe.unet.flops_per_view
-    algo1 = algo_block(pipe.unet, 1, unet_ms, EMU_PEAK[args.precision], args.tile_skip) if args.precision == 'f32' else {}
+    traffic, tinfo = pmc_traffic_per_step(args, views_per_step=1)
+    tf = flops_view / (unet_ms * 1e-3) / 1e12
+    algo1 = (algo_block(pipe.unet, 1, unet_ms, EMU_PEAK[args.precision], args.tile_skip, tf, tinfo) if args.precision == 'f32'
+             else {'achieved': tf, 'peak': EMU_PEAK[args.precision], 'unit': 'TFLOP/s', 'frac': tf / EMU_PEAK[args.precision]})
     del pipe
     # ... and three (one more private stream / activation set; a fourth would share a hardware queue: slower again)
     pipe3 = make_pipeline(sc, args, dev, 1, inflight=3)
@@ -364,9 +403,6 @@ def single_view_block(sc, args, dev):
     dt_fly3 = (time.perf_counter() - t0) / n1
     same3 = float((hs.image - seq_last).abs().max())
     del pipe3
-    tf = flops_view / (unet_ms * 1e-3) / 1e12
-    peak = EMU_PEAK[args.precision]
-    traffic, tinfo = pmc_traffic_per_step(args, views_per_step=1)
     return {
         'views_per_call': 1, 'views': n1,
         'workload': 'test_rnr.py:265-393: spiral_step720 views in order, one view per call, %dx%d, full HIP RenderingNet' % (args.img_size, args.img_size),
@@ -374,8 +410,7 @@ def single_view_block(sc, args, dev):
         'roofline': {'bound': 'mfma', 'kernel': 'conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
                                                   '64^2 -> 32^2 stride-2 layer; everywhere else the BatchNorm finalise and the split-K combine '
                                                   'happen inside the conv launch; HIP events bracket the U-Net stage of every call)',
-                     'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'stage_ms_per_view': unet_ms,
-                     **algo1, **sustained_block(args.precision, algo1.get('executed_tflops', tf)),
+                     **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
                      'alg_flops_per_view': flops_view, 'traffic': traffic,
                      'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)', **tinfo},
         'two_calls_in_flight': {'frames_per_s': 1.0 / dt_fly, 'ms_per_frame': dt_fly * 1e3,
@@ -388,11 +423,51 @@ def single_view_block(sc, args, dev):
     }
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` WITHOUT a launcher: become the launcher.  Starts N copies of this command line, one per GPU,
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (127.0.0.1, a port the kernel hands out), passes their
+    stdout / stderr through (rank 0 prints the JSON line), and returns the worst exit code; when one rank dies the others are
+    terminated by their exact PIDs so that a broken rendezvous cannot hang the launch."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RNR_BENCH_SELF_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:
+                    q.terminate()
+    return rc
+
+
 def main(argv=None):
     args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain launch asking for N GPUs: this process becomes the launcher of N ranks (one per GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a number for a '
+                         'job of another size' % (args.gpus, world))
     stub = args.stub_pipeline
     if stub:
         dev = torch.device('cpu')
@@ -491,7 +566,15 @@ def main(argv=None):
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    n_ranks_seen = dist.get_world_size() if use_dist else 1
+    # ranks that actually took part: every rank adds 1 through the process group (not dist.get_world_size(), which only
+    # repeats the environment); a mismatch with --gpus is a failed run, not a number
+    n_ranks_seen = 1
+    if use_dist:
+        cnt = torch.ones(1, device=dev, dtype=torch.int64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        n_ranks_seen = int(cnt.item())
+    if n_ranks_seen != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but %d ranks took part' % (args.gpus, n_ranks_seen))
     # executed FLOPs: the live U-Net minus the out-layer tiles skipped because no pixel of them is ever read
     skipped, flops_step, n_conv, flops_view = 0.0, 0.0, 0, 0.0
     if not stub:
@@ -504,12 +587,14 @@ def main(argv=None):
         n_conv = len(pipe.unet.steps)
     achieved_tf = flops_step / (unet_ms * 1e-3) / 1e12
     peak_tf = EMU_PEAK[args.precision]
-    algo8 = algo_block(pipe.unet, V, unet_ms, peak_tf, args.tile_skip) if (not stub and args.precision == 'f32') else {}
+    algo8 = {'achieved': achieved_tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': achieved_tf / peak_tf}
     dtype = {'f32': 'f32', 'bf16x6': 'f32 emulated on bf16 MFMA (bf16x6)', 'f16x3': 'f32 emulated on f16 MFMA (f16x3)'}[args.precision]
 
     res = None
     if rank == 0:
         traffic, traffic_info = (None, {}) if stub else pmc_traffic_per_step(args)
+        if not stub and args.precision == 'f32':
+            algo8 = algo_block(pipe.unet, V, unet_ms, peak_tf, args.tile_skip, achieved_tf, traffic_info)
         try:
             rccl = '.'.join(str(x) for x in torch.cuda.nccl.version()) if not stub else None
         except Exception:       # noqa: BLE001 - version probing must never fail a run
@@ -529,14 +614,13 @@ def main(argv=None):
                        'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world,
                        'conv_algo': None if stub else pipe.unet.conv_algo},
             'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
-                         'achieved': achieved_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / peak_tf, **algo8, 'traffic': traffic,
+                         **algo8, 'traffic': traffic,
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
                          **traffic_info,
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
-                         **sustained_block(args.precision, algo8.get('executed_tflops', achieved_tf)),
+                         **sustained_block(args.precision, algo8['achieved']),
                          'out_layer_tiles_skipped': skipped,
-                         'flops_note': 'executed FLOPs = %.1f GFLOP/view live U-Net minus the out-layer pixel tiles that hold no '
+                         'flops_note': 'alg_flops_per_step (direct form) = %.1f GFLOP/view live U-Net minus the out-layer pixel tiles that hold no '
                                        'foreground pixel when --tile-skip is given (never read: the ray renderer zeroes background)'
                                        % (flops_view / 1e9)},
         }

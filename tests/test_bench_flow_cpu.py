@@ -46,6 +46,56 @@ def test_bench_control_flow_world2_gloo(V, steps, warm):
     assert gc['gathered_shape'] == [2 * V, 3, 16, 16]
 
 
+def _plain_env():
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'RNR_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    return env
+
+
+def test_plain_launch_with_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no rank environment (the form the driver uses for N = 1): the file starts
+    the two ranks itself; the JSON says n_gpus 2 and n_ranks_seen 2 (counted through the process group) and the gathered frame
+    buffer holds both ranks' poses (--gpus used to be parsed and ignored — one rank, n_gpus 1)."""
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--stub-pipeline', '--img-size', '16', '--steps', '3',
+                        '--warmup', '1', '--views-per-step', '2', '--check-gather'], cwd=ROOT, env=_plain_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['n_ranks_seen'] == 2 and res['stub'] is True
+    assert res['gather_check']['ok'] is True and res['gather_check']['gathered_shape'] == [4, 3, 16, 16]
+    assert abs(res['value'] - 3 * 2 * 2 / (res['ms_per_step'] * 1e-3 * 3)) < 1e-6 * res['value']
+
+
+def test_plain_launch_with_gpus_1_is_one_process():
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--stub-pipeline', '--img-size', '16', '--steps', '2',
+                        '--warmup', '1', '--views-per-step', '2'], cwd=ROOT, env=_plain_env(), capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert res['n_gpus'] == 1 and res['n_ranks_seen'] == 1
+
+
+def test_launcher_world_size_must_equal_gpus():
+    """A launcher that started another number of ranks than --gpus says is an error exit, never a bench line."""
+    env = dict(_plain_env(), RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29691')
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--stub-pipeline', '--img-size', '16', '--steps', '1',
+                        '--warmup', '0'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]
+
+
+def test_plain_launch_propagates_a_failing_rank():
+    """The ranks of a self-launched job die (a negative image size passes the launcher's argparse and raises in the ranks when
+    they allocate their frame buffers): the launcher returns non-zero and prints no JSON line."""
+    p = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--stub-pipeline', '--img-size', '-1', '--steps', '1',
+                        '--warmup', '0'], cwd=ROOT, env=_plain_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]
+
+
 def test_bench_gathered_frames_are_the_right_poses():
     """The frames rank r contributes at step s are poses (s * world + r) * V ... + V of the shared pose list, and the gathered
     buffer holds rank 0's block first: checked against the stub's pose encoding, inside one process group of two ranks."""
