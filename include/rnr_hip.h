@@ -362,7 +362,10 @@ int rnr_conv2d_fused(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr
  *                    straight from the MFMA accumulators (LDS transpose, 26 columns per sum): 12 bytes per pixel leave the
  *                    kernel instead of 320.  Only the exact-fp32 3x3 convolution on the 80-column plan (65 <= c_out <= 80,
  *                    c_out = 3 x rays, map width a multiple of 32, height of 8); anything else returns an error — run
- *                    rnr_conv2d_masked + rnr_ray_render there.  tile_mask as in rnr_conv2d_masked (skipped tiles get 0).
+ *                    rnr_conv2d_masked + rnr_ray_render there.  tile_mask as in rnr_conv2d_masked (skipped tiles get 0), laid
+ *                    out for the DIRECT plan's 32 x 8-pixel tiles: RNR_CONV_WINOGRAD in d->flags is ignored by this entry
+ *                    point, so build the mask with rnr_conv_active_tiles / rnr_conv_tile_count from the descriptor with
+ *                    that flag cleared (with it set those describe the Winograd out layer's 16 x 4-pixel tiles).
  * Differs from rnr_ray_render in summation order only (<= 1e-6 on frames in [0, 2]).
  */
 int rnr_ray_weights(const float* net_in, int c_pad, const float* alpha, const float* lp, int lp_h, int lp_w, int num_spec,

@@ -162,6 +162,19 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //     (its own included: the sum does not depend on who arrives last) with sc1 loads and runs the normal epilogue.
 // Counters and statistics are zero before and after every call; the host zeroes them once.
 // ------------------------------------------------------------------------------------------------
+// REQUIRED ASSUMPTIONS of the fence-free hand-off (checked below at compile time as far as they can be; tested by
+// tests/test_gpu_unet.py::test_conv_fused_equals_separate_launches and scripts/t_fused_stress.py on the hardware):
+//   (1) gfx950 acknowledges a write-through (sc1) buffer store and a no-return agent-scope atomic — i.e. decrements vmcnt —
+//       only once it has reached the coherence point (the memory-side L2 / MALL path all XCDs share), so "s_waitcnt
+//       vmcnt(0); s_barrier; ticket" orders every lane's publication before the ticket without a release fence;
+//   (2) bit 4 (value 16) of the aux operand of the raw-buffer intrinsics is sc1 on this target: loads bypass the
+//       non-coherent caches, stores write through, which stands in for the acquire side;
+//   (3) the compiler keeps the buffer intrinsics on their side of the `asm volatile(... "memory")` + __syncthreads pair.
+// None of this is portable to another target or to a partition mode in which the XCDs do not share a coherence point; the
+// file therefore refuses to compile device code for anything but gfx950.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "conv.hip: the producer-side BatchNorm / split-K hand-off relies on gfx950 memory semantics (see above); gfx950 only"
+#endif
 #define RNR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 typedef unsigned int uintx4_t __attribute__((__vector_size__(4 * sizeof(unsigned int))));
 constexpr int AUX_SC1 = 16;         // write-through / L1-bypassing buffer access
@@ -828,9 +841,7 @@ conv_halo_kernel(const ConvParams P) {
             for (int u = 0; u < APS; u++) {
                 const int j = t * APS + u;
                 av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
                 if (next_chunk && j < APT) av[u] = load_a(csn, j);
-#endif
             }
             // halo pixel of output row (wave_m*WM + i), lane x for this tap: compile-time part here, the parity shift
             // of the transposed conv and the wave's row block are in a_lane
@@ -865,7 +876,6 @@ conv_halo_kernel(const ConvParams P) {
                         acc16[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av16[e], bv[e], acc16[sb], 0, 0, 0);
                 }
             }
-#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
             // the slice fetched HDIST - 1 taps ago goes to LDS now (HDIST = 2: two taps of MFMAs cover the HBM latency)
             const int ts = t - (HDIST - 1);
             if (ts >= 0) {
@@ -876,9 +886,7 @@ conv_halo_kernel(const ConvParams P) {
                         store_a(csn, avr[ts % (HDIST < 2 ? 2 : HDIST)][u], j, abuf ^ 1);
                 }
             }
-#endif
         }
-#if !defined(RNR_ABLATE_NOLOAD) && !defined(RNR_ABLATE_NOLOAD_A)
         // slices fetched during the last HDIST - 1 taps
 #pragma unroll
         for (int ts = TAPS - (HDIST - 1); ts < TAPS; ts++) {
@@ -890,7 +898,6 @@ conv_halo_kernel(const ConvParams P) {
                     store_a(csn, avr[ts % (HDIST < 2 ? 2 : HDIST)][u], j, abuf ^ 1);
             }
         }
-#endif
         if (TAPS & 1) breg[0] = breg[1];
         __syncthreads();                    // everybody is done reading this step's halo; the next one is complete
     }
@@ -1035,13 +1042,8 @@ conv_halo_kernel(const ConvParams P) {
 }
 
 // (r03 experiment, measured and not adopted: conv_halo_kernel as a persistent tile loop with next-tile prefetch — -1.4 % at 8
-// views per launch, DESIGN.md §3.3.  Kernel and launcher live in conv_persist_experiment.inc and are compiled only with
-// -DRNR_EXPERIMENT_PERSIST.)
-#ifdef RNR_EXPERIMENT_PERSIST
-#define RNR_PERSIST_PART 1
-#include "conv_persist_experiment.inc"
-#undef RNR_PERSIST_PART
-#endif
+// views per launch, DESIGN.md §3.3, profiles/r03_layer_time_persist_ab_*.  The source is kept outside the product tree:
+// scripts/experiments/conv_persist_experiment.inc, with the three inclusion points it needs.)
 
 // ------------------------------------------------------------------------------------------------
 // fp32 emulation on the 16-bit matrix cores (opt-in; gfx950's fp32-input MFMA runs at 1/16 of the 16-bit rate).
@@ -1308,7 +1310,6 @@ conv_halo_emu_kernel(const ConvParams P) {
             // ---- operands of the NEXT tap / chunk are requested before this tap's MFMAs ----
             if (t < TAPS - 1) load_b(b[(t + 1) & 1], c, t + 1);
             else if (next_chunk) load_b(b[TAPS & 1], c + 1, 0);
-#ifndef RNR_ABLATE_EMU_NOHALO
             if (next_chunk) {
                 if (t < NGROUPS) {
 #pragma unroll
@@ -1323,7 +1324,6 @@ conv_halo_emu_kernel(const ConvParams P) {
                     }
                 }
             }
-#endif
             int aoff;
             if (KIND == 0) aoff = (t / 3) * HWD + (t % 3);
             else if (KIND == 1) aoff = (t >> 1) * HWD + (t & 1);
@@ -1345,7 +1345,6 @@ conv_halo_emu_kernel(const ConvParams P) {
                             acc[i][j] = F::mfma(a[i], b[t & 1][tb][j], acc[i][j]);
             }
         }
-#ifndef RNR_ABLATE_EMU_NOHALO
         if (next_chunk && NGROUPS == TAPS) {        // the slice loaded during the last tap
 #pragma unroll
             for (int u = 0; u < SPT; u++) {
@@ -1353,7 +1352,6 @@ conv_halo_emu_kernel(const ConvParams P) {
                 if (j < APT && tid + CTHREADS * j < ASLOTS) store_a(csn, av[(TAPS - 1) & 1][u], j, a_wr);
             }
         }
-#endif
         if (TAPS & 1) {
 #pragma unroll
             for (int term = 0; term < NT; term++)
@@ -1482,11 +1480,6 @@ static void launch_halo_cfg(const dim3 grid, const ConvParams& P, hipStream_t st
     hipLaunchKernelGGL((conv_halo_kernel<KIND, WAVES_M, WAVES_N, WM, WN, R16, TW>), grid, dim3(CTHREADS), lds, st, P);
 }
 
-#ifdef RNR_EXPERIMENT_PERSIST
-#define RNR_PERSIST_PART 2
-#include "conv_persist_experiment.inc"
-#undef RNR_PERSIST_PART
-#endif
 
 // out[m,c] = sum_s slab[s][m,c]; statistics per view.  One float4 of an output row per thread and pass: 16 rows x 64 columns
 // per pass of a 256-thread workgroup, rpw / 16 passes (the host picks rpw = 16 ... 128 rows per workgroup so that big maps do
@@ -1773,6 +1766,13 @@ static int wino_splitk(long wgs, int min_wgs, int chunks) {
     int sk = (int)((min_wgs + wgs - 1) / wgs);
     const int max_sk = chunks / RNR_WINO_SPLIT_MIN_CHUNKS < 8 ? chunks / RNR_WINO_SPLIT_MIN_CHUNKS : 8;
     if (sk > max_sk) sk = max_sk;
+    if (sk >= 2) {
+        // no empty trailing slice: the kernels give every slice ceil(chunks / sk) chunks, so e.g. 29 chunks cut 7 ways (5 per
+        // slice) would leave slice 6 starting at chunk 30 — nothing to add, but its weight look-ahead would read past the
+        // column tile's image.  Keep the slice length, drop the empty slices.
+        const int per = (chunks + sk - 1) / sk;
+        sk = (chunks + per - 1) / per;
+    }
     if (sk < 2 || wgs * sk < RNR_WINO_SPLIT_MIN_WGS) return 0;
     return sk;
 }
@@ -1950,16 +1950,6 @@ static void launch_halo_emu(const ConvPlan& pl, const dim3 grid, const ConvParam
 template <int KIND>
 static void launch_halo(const ConvPlan& pl, const ConvParams& P, hipStream_t st) {
     const dim3 grid((unsigned)(pl.mtiles * pl.ntiles * pl.splitk * pl.par));
-#ifdef RNR_EXPERIMENT_PERSIST
-    // the big configurations run as persistent tile loops when they have more tiles than co-resident workgroups
-    if (pl.tw == 32 && pl.splitk == 1) {
-        const long total = (long)grid.x;
-        if (pl.cfg == 0 && launch_halo_persist_cfg<KIND, 4, 1, 2, 2, 0>(total, P, st)) return;
-        if (pl.cfg == 1 && launch_halo_persist_cfg<KIND, 4, 1, 2, 2, 1>(total, P, st)) return;
-        if (pl.cfg == 2 && pl.bm == 256 && launch_halo_persist_cfg<KIND, 2, 2, 4, 2, 0>(total, P, st)) return;
-        if (pl.cfg == 2 && pl.bm == 128 && launch_halo_persist_cfg<KIND, 2, 2, 2, 2, 0>(total, P, st)) return;
-    }
-#endif
     if (pl.cfg == 4) launch_halo_cfg<KIND, 4, 1, 1, 2, 0>(grid, P, st);                         // 32 x 4 pixel tiles, 64 columns
     else if (pl.cfg == 3 && pl.tw == 16) launch_halo_cfg<KIND, 2, 2, 1, 1, 0, 16>(grid, P, st);      // 16 x 4 pixel tiles, 64 columns
     else if (pl.cfg == 3) launch_halo_cfg<KIND, 2, 2, 1, 1, 0>(grid, P, st);                    // 32 x 2 pixel tiles, 64 columns
@@ -2328,7 +2318,9 @@ extern "C" int rnr_conv2d_ray(const rnr_conv_desc* d, const rnr_conv_src* src0, 
                 "rnr_conv2d_ray: only the exact-fp32 3x3 out layer on the 80-column plan (65 <= c_out <= 80, c_out = 3 x rays, map "
                 "width a multiple of 32, height of 8) has the ray-renderer epilogue; run rnr_conv2d_masked + rnr_ray_render otherwise");
     g_ray = {ray_w, bias, image};
-    const int rc = conv2d_run(d, src0, src1, weight_packed, image /* never written as out_raw */, nullptr, nullptr, nullptr, 0,
+    // the stripped descriptor goes down: the plan, the tile count and therefore the layout tile_mask is read in are those of
+    // the direct 32 x 8-pixel tiles whatever flags the caller's descriptor carries
+    const int rc = conv2d_run(&dd, src0, src1, weight_packed, image /* never written as out_raw */, nullptr, nullptr, nullptr, 0,
                               num_views, in_h, in_w, nullptr, 0, tile_mask, stream);
     g_ray = {nullptr, nullptr, nullptr};
     return rc;

@@ -211,7 +211,6 @@ shade_inputs_kernel(const ShadeParams P) {
     const bool tex_early = SH_PIX * quads <= SH_THREADS - 64;
     float4 tex_acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int tex_p = -1, tex_q = 0;
-#ifndef RNR_ABLATE_SH_NOTEX
     if (tex_early && tid >= 64 && tid - 64 < SH_PIX * quads) {
         const int i = tid - 64;
         tex_p = i / quads; tex_q = i - tex_p * quads;
@@ -220,7 +219,6 @@ shade_inputs_kernel(const ShadeParams P) {
         if (pix < P.npix) { u = P.uv_map[pix * 2 + 0]; v = P.uv_map[pix * 2 + 1]; }
         tex_acc = texture_quad(P, u, v, tex_q, quads);
     }
-#endif
 
     // ---- phase 0: one lane per pixel: TBN, view direction, SH basis ----
     if (tid < SH_PIX) {
@@ -288,9 +286,6 @@ shade_inputs_kernel(const ShadeParams P) {
     // fastest every lane of a wave hit one of two banks (row stride 112 floats = 16 mod 32): 16-way conflicts,
     // 72 M conflict cycles per dispatch in the round-1 profile.
     const float inv_rays = 1.0f / (float)n_rays;
-#ifdef RNR_ABLATE_SH_NORAYS
-    if (false)
-#endif
     for (int i = tid; i < SH_PIX * n_rays; i += SH_THREADS) {
         const int p = (int)(((float)i + 0.5f) * inv_rays), r = i - p * n_rays;      // exact i / n_rays for i < 2^20
 
@@ -343,7 +338,6 @@ shade_inputs_kernel(const ShadeParams P) {
         if (((c_geo + 6) & 3) == 0) *reinterpret_cast<float4*>(tp) = acc;     // one ds_write_b128 (rows are 16-byte aligned)
         else { tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w; }
     };
-#ifndef RNR_ABLATE_SH_NOTEX
     if (tex_early) {
         if (tex_p >= 0) finish_quad(tex_acc, tex_p, tex_q);
     } else {
@@ -353,7 +347,6 @@ shade_inputs_kernel(const ShadeParams P) {
             finish_quad(texture_quad(P, g[12], g[13], q, quads), p, q);
         }
     }
-#endif
     __syncthreads();
 
     // ---- phase 3: one coalesced sweep of the tile to HBM ----
@@ -361,9 +354,6 @@ shade_inputs_kernel(const ShadeParams P) {
     const int n4 = (int)(valid_pix * cp / 4);
     float4* dst = reinterpret_cast<float4*>(P.net_in + pix0 * cp);
     const float4* src = reinterpret_cast<const float4*>(tile);
-#ifdef RNR_ABLATE_SH_NOSTORE
-    if (blockIdx.x == 0x7fffffff)
-#endif
     for (int i = tid; i < n4; i += SH_THREADS) dst[i] = src[i];
     if (P.neural_img) {  // [N, C, H, W] copy for the API (TextureMapper.forward's return value)
         const int hw = P.H * P.W;
@@ -537,9 +527,6 @@ ray_render_kernel(const RayParams P) {
         c0[k] = c1[k] = c2[k] = 0.f;
         if (live[k]) {
             const Taps& t = tp[k];
-#ifdef RNR_ABLATE_RAY_FIXEDTAP
-            const float* l00 = P.lp + (unsigned)(sub * 3); const float* l10 = l00 + 3; const float* l01 = l00 + 6; const float* l11 = l00 + 9;
-#else
             // texel offsets with 24-bit multiplies (full rate; v_mul_lo_u32 runs at a quarter of it): the probe has far
             // fewer than 2^24 floats
             const unsigned r0 = __umul24((unsigned)t.y0, (unsigned)lp_w3), r1 = __umul24((unsigned)t.y1, (unsigned)lp_w3);
@@ -548,7 +535,6 @@ ray_render_kernel(const RayParams P) {
             const float* l10 = P.lp + (r1 + q0);
             const float* l01 = P.lp + (r0 + q1);
             const float* l11 = P.lp + (r1 + q1);
-#endif
             // (explicit FMAs, see fast_atan2f; the reference's torch ops round every product, <= 1 ulp apart)
             const float col0 = __builtin_fmaf(l11[0], t.w11, __builtin_fmaf(l01[0], t.w01, __builtin_fmaf(l10[0], t.w10, l00[0] * t.w00)));
             const float col1 = __builtin_fmaf(l11[1], t.w11, __builtin_fmaf(l01[1], t.w01, __builtin_fmaf(l10[1], t.w10, l00[1] * t.w00)));

@@ -194,8 +194,12 @@ class RNRPipeline:
                 lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
                 image = sl.images[sl.flip][:N]
                 sl.flip ^= 1
-                self._render_group(0, 0, N, proj.contiguous(), pose.contiguous(), proj_inv.contiguous(), R_inv.contiguous(),
-                                   lp, image, lambda name: None, slot=sl)
+                args = [t.contiguous() for t in (proj, pose, proj_inv, R_inv)]
+                for t in args:
+                    # the caller's tensors are read by kernels of THIS stream: tell the caching allocator, or a caller that
+                    # drops its pose tensors right after submit() gets their memory recycled under the running kernels
+                    t.record_stream(sl.stream)
+                self._render_group(0, 0, N, *args, lp, image, lambda name: None, slot=sl)
                 ev = torch.cuda.Event()
                 ev.record(sl.stream)
             return FrameHandle(image, ev)

@@ -38,7 +38,7 @@ DEFAULT_CONV_ALGO = 'winograd'
 class UNetPlan:
     def __init__(self, state_dict, in_channels, out_channels, nf0, num_down, img_hw, max_views, device,
                  prefix='net.', in_c_pad=None, bn_mode='batch', share_weights_with=None, precision='f32',
-                 update_running_stats=False, check_finite=False, conv_algo=None):
+                 update_running_stats=False, check_finite=None, conv_algo=None):
         """bn_mode 'batch': BatchNorm2d in train mode with PER-VIEW batch statistics — what test_rnr.py:229-233 forces,
         evaluated the way the reference evaluates it (one view per call); a batch of N poses is N independent frames.
         'batch_all': train-mode BatchNorm2d exactly as torch computes it for ONE call with an [N,C,H,W] input: statistics
@@ -60,6 +60,16 @@ class UNetPlan:
             raise ValueError("precision must be one of %s" % sorted(_lib.EMU_FLAGS))
         if bn_mode not in ('batch', 'batch_all', 'running'):
             raise ValueError("bn_mode must be 'batch', 'batch_all' or 'running'")
+        if share_weights_with is not None:
+            # the donor's packed buffers are used as they are: their layout (direct image only / + Winograd image / 16-bit
+            # term image) is fixed by the donor's conv_algo and precision, so both are inherited and a contradicting
+            # explicit choice is an error, not a silent read past the end of the donor's buffers
+            want_algo = conv_algo if precision == 'f32' else 'direct'
+            if want_algo is not None and want_algo != share_weights_with.conv_algo:
+                raise ValueError("share_weights_with: conv_algo %r differs from the donor plan's %r" % (conv_algo, share_weights_with.conv_algo))
+            if precision != share_weights_with.precision:
+                raise ValueError("share_weights_with: precision %r differs from the donor plan's %r" % (precision, share_weights_with.precision))
+            conv_algo = share_weights_with.conv_algo
         if conv_algo is None:
             conv_algo = os.environ.get('RNR_CONV_ALGO') or DEFAULT_CONV_ALGO
         if conv_algo not in ('direct', 'winograd'):
@@ -72,7 +82,11 @@ class UNetPlan:
         # f16x3 splits activations into fp16 terms: |act(scale * x + shift)| must stay below 65504, which BatchNorm outputs do
         # but the four un-normalised convolutions of the innermost block need not for exotic weights.  check_finite=True makes
         # every forward verify (one host synchronisation) that its result holds no inf / NaN — a debugging aid, off by default.
-        self.check_finite = bool(check_finite)
+        # Winograd spreads an inf / NaN activation over the whole 2 x 2 tiles whose patch contains it (a direct convolution
+        # confines it to the windows that contain it; include/rnr_hip.h, RNR_CONV_WINOGRAD).  check_finite=None (the default)
+        # therefore checks the FIRST forward of a Winograd plan — input and output, one host synchronisation, once — and warns;
+        # True checks every forward and raises; False never checks.
+        self.check_finite = 'first' if (check_finite is None and conv_algo == 'winograd') else bool(check_finite)
         self.L = _lib.load()
         self.dev = device
         self.N = int(max_views)
@@ -102,6 +116,8 @@ class UNetPlan:
                 desc.flags |= _lib.CONV_WINOGRAD
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
+                if packed.numel() != self.L.rnr_packed_weight_floats(ctypes.byref(desc)):
+                    raise ValueError('share_weights_with: layer %d of the donor plan was packed for another descriptor' % len(self.steps))
             else:
                 w = g(wkey)
                 packed = torch.empty(self.L.rnr_packed_weight_floats(ctypes.byref(desc)), dtype=torch.float32, device=device)
@@ -274,7 +290,15 @@ class UNetPlan:
                     s['sync'].zero_()
             raise
         res = self.out.data[:n] if ray is None else ray[1]
-        if self.check_finite and mask is None and not bool(torch.isfinite(res).all()):
+        if self.check_finite == 'first' and not torch.cuda.is_current_stream_capturing():
+            self.check_finite = False
+            if not (bool(torch.isfinite(net_in[:n]).all()) and (mask is not None or bool(torch.isfinite(res).all()))):
+                import warnings
+                warnings.warn("UNetPlan(conv_algo='winograd'): non-finite values in the network input or output of the first "
+                              "call; the Winograd kernels spread an inf / NaN activation over whole 2 x 2 output tiles where a "
+                              "direct convolution confines it to the windows that contain it (include/rnr_hip.h, "
+                              "RNR_CONV_WINOGRAD) — use conv_algo='direct' to localise it", RuntimeWarning, stacklevel=2)
+        elif self.check_finite is True and mask is None and not bool(torch.isfinite(res).all()):
             raise FloatingPointError('UNetPlan(precision=%r): non-finite values in the network output (f16x3 needs activations '
                                      'below 65504: include/rnr_hip.h, RNR_CONV_F32_EMU_F16X3)' % self.precision)
         return res

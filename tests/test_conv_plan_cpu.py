@@ -79,3 +79,24 @@ def test_split_winograd_grids_have_workspace_and_sync():
     assert L.rnr_conv_tile_count(ctypes.byref(desc(0, (64, 64), 78)), 1, 512, 512) == (512 // 8) * (512 // 32)
     # (one 512 x 512 view of a 64-column layer: the direct plan uses 32 x 4 pixel tiles)
     assert L.rnr_conv_tile_count(ctypes.byref(desc(0, (64,), 64, _lib.CONV_WINOGRAD)), 1, 512, 512) == (512 // 4) * (512 // 32)
+
+
+@pytest.mark.parametrize('kind,hw,cout', [(0, 64, 64), (1, 128, 256), (2, 64, 64)])
+def test_split_winograd_grids_have_no_empty_slice(kind, hw, cout):
+    """with ceil(chunks / sk) chunks per slice some chunk counts (29 cut 7 ways: 5 per slice) left a trailing slice
+    that starts behind the last chunk; its weight look-ahead would then read past the column tile's image.  The plan keeps
+    the slice length and drops such slices: (sk - 1) * ceil(chunks / sk) < chunks for every chunk count."""
+    L = _lib.load()
+    oh = hw // 2 if kind == 1 else (2 * hw if kind == 2 else hw)
+    seen_split = 0
+    for chunks in range(4, 70):
+        d = desc(kind, (16 * chunks,), cout, _lib.CONV_WINOGRAD)
+        if L.rnr_conv_algorithm(ctypes.byref(d), 1, hw, hw) not in (1, 2):
+            continue
+        sk = L.rnr_conv_workspace_bytes(ctypes.byref(d), 1, hw, hw) // (oh * oh * cout * 4)
+        if sk < 2:
+            continue
+        seen_split += 1
+        per = -(-chunks // sk)
+        assert (sk - 1) * per < chunks and per >= 4, (chunks, sk, per)
+    assert seen_split > 10

@@ -32,7 +32,7 @@ def test_bench_under_torchrun_rccl_gather():
     assert res['gather_check']['backend'] == 'nccl'
     assert res['gather_check']['gathered_shape'] == [2, 3, 512, 512]
     assert res['value'] > 10.0 and res['scaling'] == 'weak'
-    assert res['roofline']['frac'] > 0.1 and res['cpu_baseline'] is None
+    assert 0.1 < res['roofline']['frac'] <= 1.0 and res['cpu_baseline'] is None and res['n_ranks_seen'] == 1
 
 
 def test_bench_plain_launch_forced_dist():
@@ -58,14 +58,16 @@ def test_bench_single_view_block():
     assert sv['views_per_call'] == 1 and sv['views'] == 24
     assert sv['frames_per_s'] > 100.0 and abs(sv['frames_per_s'] * sv['ms_per_frame'] - 1000.0) < 1.0
     r = sv['roofline']
-    assert r['bound'] == 'mfma' and 0.3 < r['frac'] < 2.25 and r['peak'] == 157.3
-    assert abs(r['achieved'] - r['alg_flops_per_view'] / (r['stage_ms_per_view'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
-    # frac counts the algorithmic (direct-form) FLOPs; what the matrix cores execute (fewer multiplications in the Winograd
-    # layers) stays below the peak, nominal and sustained
+    # frac counts what the matrix cores EXECUTE (fewer multiplications in the Winograd layers): a utilisation, <= 1 by
+    # construction, nominal and sustained; the algorithmic (direct-form) figure is reported beside it
+    assert r['bound'] == 'mfma' and 0.3 < r['frac'] < r['frac_of_sustained'] < 1.0 and r['peak'] == 157.3
+    assert abs(r['achieved'] - r['executed_mfma_flops'] / (r['stage_ms_per_view'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
+    assert abs(r['effective_tflops_direct_form'] - r['alg_flops_per_view'] / (r['stage_ms_per_view'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
     assert r['conv_algo'] == 'winograd' and sum(r['layers_direct_winograd3x3_winograd2x2']) == 22
     assert r['layers_direct_winograd3x3_winograd2x2'][1] >= 8 and r['layers_direct_winograd3x3_winograd2x2'][2] >= 3
-    assert r['executed_mfma_flops'] < r['alg_flops_per_view'] and r['frac_executed'] < r['frac']
-    assert 0.3 < r['frac_executed'] < r['frac_of_sustained'] < 1.0
+    assert r['executed_mfma_flops'] < r['alg_flops_per_view'] and 1.5 < r['algorithmic_speedup'] < 2.25
+    if r.get('executed_flops_from_pmc'):
+        assert 0.95 < r['executed_flops_pmc_over_model'] < 1.05
     fly = sv['two_calls_in_flight']
     assert fly['frames_per_s'] > 100.0 and fly['max_abs_diff_vs_sequential_last_frame'] < 2e-6
     assert res['n_ranks_seen'] == 1 and 'stages' in res

@@ -433,6 +433,39 @@ def test_calls_in_flight_give_the_sequential_frames():
         mk(inflight=2, streams=2)
 
 
+def test_submit_keeps_dropped_pose_tensors_alive():
+    """A per-view loop that builds its pose tensors inside the iteration and drops them right after submit():
+    the slot's side stream still reads them, so submit() must record that use with the caching allocator.  Here every call's
+    poses are fresh allocations that are deleted at once and whose freed blocks are immediately re-allocated and filled with
+    garbage on the caller's stream; the frames must be those of the original poses."""
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    sc = testing.tiny_scene(img_size=128, nf0=8, tex_size=64, tex_ch=24, nlat=31, nlon=62, seed=7)
+    mk = lambda **kw: RNRPipeline(sc['mesh'], 128, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], sc['lp'], nf0=8,
+                                  max_views=1, device=DEV, **kw)
+    seq, fly = mk(), mk(inflight=3)
+    ids = [3, 50, 111, 222, 333, 444]
+    host = {k: T(x) for k, x in scene.spiral_views(128, ids).items()}
+    want = []
+    for i in range(len(ids)):
+        p = {k: x[i:i + 1].to(DEV) for k, x in host.items()}
+        want.append(seq.render(p['proj'], p['pose'], p['proj_inv'], p['R_inv']).clone())
+    torch.cuda.synchronize()
+    handles = []
+    for i in range(len(ids)):
+        p = {k: x[i:i + 1].to(DEV) for k, x in host.items()}          # fresh blocks of the caller's stream
+        shapes = {k: x.shape for k, x in p.items()}
+        handles.append(fly.submit(p['proj'], p['pose'], p['proj_inv'], p['R_inv']))
+        del p
+        # same-sized allocations on the caller's stream: without record_stream the allocator hands the poses' blocks back
+        junk = [torch.full(tuple(sh), float('nan'), device=DEV) for sh in shapes.values() for _ in range(4)]
+        del junk
+    got = [h.wait().clone() for h in handles]
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert bool(torch.isfinite(b).all()) and float((a - b).abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize('skip', [False, True])
 def test_ray_renderer_in_the_out_layer_epilogue(skip):
     """RNRPipeline(fuse_ray=True): ops.ray_weights + rnr_conv2d_ray (bias + tanh + the 26-ray sum in the out layer's epilogue,
