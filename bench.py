@@ -273,7 +273,7 @@ def pmc_mfma_flops_per_step(info):
     """Executed MFMA FLOPs per step counted by the hardware: SUM SQ_INSTS_MFMA x FLOPs per wave instruction (4096 for
     v_mfma_f32_32x32x2_f32, 2048 for the out layer's v_mfma_f32_16x16x4_f32 kernel) over the conv kernels of the SAME PMC
     file roofline.traffic comes from, / (steps + warm-up) of that profile run.  None without such a file / counter."""
-    path = info.get('traffic_path')
+    path = info.pop('traffic_path', None)       # a path of this machine: used here, not printed
     if not path:
         return None
     try:
