@@ -412,7 +412,8 @@ def single_view_block(sc, args, dev):
                                                   'happen inside the conv launch; HIP events bracket the U-Net stage of every call)',
                      **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
                      'alg_flops_per_view': flops_view, 'traffic': traffic,
-                     'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)', **tinfo},
+                     'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
+                     **{k: v for k, v in tinfo.items() if k != 'traffic_path'}},
         'two_calls_in_flight': {'frames_per_s': 1.0 / dt_fly, 'ms_per_frame': dt_fly * 1e3,
                                 'max_abs_diff_vs_sequential_last_frame': same,
                                 'note': 'RNRPipeline(inflight=2).submit: throughput of the same one-view calls with two in flight '
@@ -616,7 +617,7 @@ def main(argv=None):
             'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
                          **algo8, 'traffic': traffic,
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
-                         **traffic_info,
+                         **{k: v for k, v in traffic_info.items() if k != 'traffic_path'},
                          'alg_flops_per_step': flops_step, 'stage_ms_per_step': unet_ms,
                          **sustained_block(args.precision, algo8['achieved']),
                          'out_layer_tiles_skipped': skipped,
