@@ -181,6 +181,27 @@ int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, const float*
                           int image_size, float near_, float far_, const rnr_gbuffer* out,
                           void* workspace, void* stream);
 
+/* rnr_rasterize_gbuffer for a workspace whose per-call regions rnr_frame_prepare has already cleared on the same stream
+ * (same arguments, same results; one launch fewer). */
+int rnr_rasterize_gbuffer_prepared(const rnr_mesh* mesh, const float* v_uvz, const float* pose, int num_views,
+                                   int image_size, float near_, float far_, const rnr_gbuffer* out,
+                                   void* workspace, void* stream);
+
+/*
+ * The per-call preliminaries of a frame batch in ONE launch (test_rnr.py:283-300 per view: R / t from the pose, nr.projection;
+ * render.get_TBN_map's per-face tangents, render.py:135-150; LightingSH.reconstruct_lp, network.py:622-627), plus the clearing
+ * of the rnr_rasterize_gbuffer workspace.  Every part is optional (NULL output = skipped) and bit-identical to its
+ * stand-alone entry point (rnr_project_vertices with R = pose[:, :3, :3], t = pose[:, :3, 3], no distortion / offset / scale;
+ * rnr_face_tangents; rnr_sh_reconstruct):
+ *   K [N,3,3], pose [N,4,4] -> v_uvz [N, nv, 3];   tangents [nf, 3];
+ *   lp_basis [lp_samples, lp_num_basis], lp_coeff [lp_num_basis, lp_channels] -> light_probe [lp_samples, lp_channels];
+ *   gbuffer_workspace: an rnr_gbuffer_workspace_bytes(num_views, mesh->num_faces, image_size) buffer -> cleared for
+ *   rnr_rasterize_gbuffer_prepared.
+ */
+int rnr_frame_prepare(const rnr_mesh* mesh, const float* K, const float* pose, int num_views, int image_size, float eps,
+                      float* v_uvz, float* tangents, const float* lp_basis, const float* lp_coeff, float* light_probe,
+                      int lp_samples, int lp_num_basis, int lp_channels, void* gbuffer_workspace, void* stream);
+
 /* Per-face unit tangents of render.get_TBN_map (render.py:135-150); static per mesh.  out [nf,3]. */
 int rnr_face_tangents(const rnr_mesh* mesh, float* out, void* stream);
 

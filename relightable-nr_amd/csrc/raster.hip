@@ -667,7 +667,7 @@ raster_clear_kernel(uint4* __restrict__ counters, long counter_vec, uint4* __res
 
 // fills P.tile_count / P.tile_list / P.keys.
 static int run_binning(char* ws, const float* faces, const float* faces_inv, const FaceBox* boxes, int batch, int nf, int is,
-                       RasterParams* P, hipStream_t st) {
+                       RasterParams* P, hipStream_t st, bool precleared = false) {
     const int ntiles = num_tiles(is);
     int* tile_count = reinterpret_cast<int*>(ws);
     int* wide_count = tile_count + (size_t)batch * ntiles;
@@ -679,7 +679,7 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
         align_up((size_t)batch * nf * sizeof(int), 256));
     const long total = (long)batch * nf;
     const bool splat = P->near_ >= 0.0f;            // the key order needs zp > 0, which the near test then guarantees
-    {   // both regions are 256-byte aligned and padded (bin_counter_bytes / key_bytes): whole uint4 stores
+    if (!precleared) {   // both regions are 256-byte aligned and padded (bin_counter_bytes / key_bytes): whole uint4 stores
         const long cvec = (long)(bin_counter_bytes(batch, is) / sizeof(uint4));
         const long kvec = splat ? (long)(key_bytes(batch, is) / sizeof(uint4)) : 0;
         hipLaunchKernelGGL(raster_clear_kernel, dim3((unsigned)((cvec + kvec + 255) / 256)), dim3(256), 0, st,
@@ -763,9 +763,36 @@ extern "C" size_t rnr_gbuffer_workspace_bytes(int num_views, int num_faces, int 
     return box_bytes(num_views, num_faces) + 2 * face_bytes(num_views, num_faces) + bin_bytes(num_views, num_faces, image_size);
 }
 
+// the two regions of an rnr_rasterize_gbuffer workspace that must be cleared before every call (tile / wide-list counters to
+// 0, depth keys to ~0), as whole uint4 vectors: for rnr_frame_prepare (shade.hip), which clears them in its own launch
+void rnr::gbuffer_clear_regions(void* workspace, int num_views, int num_faces, int image_size, uint4** counters, long* counter_vec,
+                                uint4** keys, long* key_vec) {
+    char* ws = reinterpret_cast<char*>(workspace) + box_bytes(num_views, num_faces) + 2 * face_bytes(num_views, num_faces);
+    *counters = reinterpret_cast<uint4*>(ws);
+    *counter_vec = (long)(bin_counter_bytes(num_views, image_size) / sizeof(uint4));
+    *keys = reinterpret_cast<uint4*>(ws + bin_counter_bytes(num_views, image_size) +
+                                     align_up((size_t)num_views * num_tiles(image_size) * BIN_CAP * sizeof(int), 256) +
+                                     align_up((size_t)num_views * num_faces * sizeof(int), 256));
+    *key_vec = (long)(key_bytes(num_views, image_size) / sizeof(uint4));
+}
+
+static int rasterize_gbuffer_impl(const rnr_mesh* mesh, const float* v_uvz, const float* pose, int num_views, int image_size,
+                                  float near_, float far_, const rnr_gbuffer* out, void* workspace, void* stream, bool precleared);
+
 extern "C" int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, const float* pose,
                                      int num_views, int image_size, float near_, float far_,
                                      const rnr_gbuffer* out, void* workspace, void* stream) {
+    return rasterize_gbuffer_impl(mesh, v_uvz, pose, num_views, image_size, near_, far_, out, workspace, stream, false);
+}
+
+extern "C" int rnr_rasterize_gbuffer_prepared(const rnr_mesh* mesh, const float* v_uvz, const float* pose,
+                                              int num_views, int image_size, float near_, float far_,
+                                              const rnr_gbuffer* out, void* workspace, void* stream) {
+    return rasterize_gbuffer_impl(mesh, v_uvz, pose, num_views, image_size, near_, far_, out, workspace, stream, true);
+}
+
+static int rasterize_gbuffer_impl(const rnr_mesh* mesh, const float* v_uvz, const float* pose, int num_views, int image_size,
+                                  float near_, float far_, const rnr_gbuffer* out, void* workspace, void* stream, bool precleared) {
     RNR_REQUIRE(mesh && v_uvz && out && workspace, "rnr_rasterize_gbuffer: null pointer argument");
     RNR_REQUIRE(mesh->v && mesh->f_v_idx && mesh->num_faces > 0 && mesh->num_vertices > 0,
                 "rnr_rasterize_gbuffer: incomplete mesh");
@@ -791,7 +818,7 @@ extern "C" int rnr_rasterize_gbuffer(const rnr_mesh* mesh, const float* v_uvz, c
     P.near_ = near_; P.far_ = far_; P.flip = 1;
     P.mesh = *mesh; P.gb = *out; P.pose = pose;
     if (int e = run_binning(ws + box_bytes(num_views, nf) + 2 * face_bytes(num_views, nf), faces, faces_inv, boxes, num_views,
-                            nf, image_size, &P, st)) return e;
+                            nf, image_size, &P, st, precleared)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<1>, dim3(tiles * tiles, num_views), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<1>");

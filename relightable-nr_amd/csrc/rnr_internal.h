@@ -21,6 +21,10 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// raster.hip: the regions of an rnr_rasterize_gbuffer workspace that are cleared per call (for rnr_frame_prepare)
+void gbuffer_clear_regions(void* workspace, int num_views, int num_faces, int image_size, uint4** counters, long* counter_vec,
+                           uint4** keys, long* key_vec);
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 #define RNR_REQUIRE(cond, ...)                     \

@@ -37,23 +37,27 @@ __device__ __forceinline__ float3 normalize3_fast(float3 a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-project_vertices_kernel(const float* __restrict__ vertices, const float* __restrict__ K,
-                        const float* __restrict__ R, const float* __restrict__ t,
-                        const float* __restrict__ dist, const float* __restrict__ offset,
-                        const float* __restrict__ scale, float* __restrict__ out, int nviews, int nv,
-                        float orig_size, float eps) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// nr.projection for vertex i of the view batch (projection.py:6-53).  POSE: R and t are read straight from the [N,4,4] pose
+// matrices (R = pose[:, :3, :3], t = pose[:, :3, 3]) — the same operands, the same arithmetic, the same bits as with the
+// separate [N,3,3] / [N,3] tensors the reference builds (test_rnr.py:283-284).
+template <bool POSE>
+__device__ __forceinline__ void project_vertex(long i, const float* __restrict__ vertices, const float* __restrict__ K,
+                                               const float* __restrict__ R, const float* __restrict__ t,
+                                               const float* __restrict__ dist, const float* __restrict__ offset,
+                                               const float* __restrict__ scale, float* __restrict__ out, int nviews, int nv,
+                                               float orig_size, float eps) {
     if (i >= (long)nviews * nv) return;
     const int n = (int)(i / nv), vi = (int)(i % nv);
     const float* p = vertices + (size_t)vi * 3;
-    const float* Rn = R + n * 9;
+    constexpr int RS = POSE ? 4 : 3;            // row stride of R
+    const float* Rn = R + n * (POSE ? 16 : 9);
     const float* Kn = K + n * 9;
+    const float t0 = POSE ? Rn[3] : t[n * 3 + 0], t1 = POSE ? Rn[7] : t[n * 3 + 1], t2 = POSE ? Rn[11] : t[n * 3 + 2];
     const float vx = p[0], vy = p[1], vz = p[2];
     // vertices . R^T + t   (projection.py:22)
-    const float x = vx * Rn[0] + vy * Rn[1] + vz * Rn[2] + t[n * 3 + 0];
-    const float y = vx * Rn[3] + vy * Rn[4] + vz * Rn[5] + t[n * 3 + 1];
-    const float z = vx * Rn[6] + vy * Rn[7] + vz * Rn[8] + t[n * 3 + 2];
+    const float x = vx * Rn[0] + vy * Rn[1] + vz * Rn[2] + t0;
+    const float y = vx * Rn[RS + 0] + vy * Rn[RS + 1] + vz * Rn[RS + 2] + t1;
+    const float z = vx * Rn[2 * RS + 0] + vy * Rn[2 * RS + 1] + vz * Rn[2 * RS + 2] + t2;
     const float xn = x / (z + eps), yn = y / (z + eps);
     float k1 = 0.f, k2 = 0.f, p1 = 0.f, p2 = 0.f, k3 = 0.f;
     if (dist) { k1 = dist[n * 5 + 0]; k2 = dist[n * 5 + 1]; p1 = dist[n * 5 + 2]; p2 = dist[n * 5 + 3]; k3 = dist[n * 5 + 4]; }
@@ -76,10 +80,18 @@ project_vertices_kernel(const float* __restrict__ vertices, const float* __restr
     out[i * 3 + 2] = z;
 }
 
-// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-face_tangents_kernel(rnr_mesh mesh, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+project_vertices_kernel(const float* __restrict__ vertices, const float* __restrict__ K,
+                        const float* __restrict__ R, const float* __restrict__ t,
+                        const float* __restrict__ dist, const float* __restrict__ offset,
+                        const float* __restrict__ scale, float* __restrict__ out, int nviews, int nv,
+                        float orig_size, float eps) {
+    project_vertex<false>((long)blockIdx.x * blockDim.x + threadIdx.x, vertices, K, R, t, dist, offset, scale, out, nviews, nv,
+                          orig_size, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void face_tangent(int i, const rnr_mesh& mesh, float* __restrict__ out) {
     if (i >= mesh.num_faces) return;
     const int32_t* vi = mesh.f_v_idx + (size_t)i * 3;
     const int32_t* ti = mesh.f_vt_idx + (size_t)i * 3;
@@ -97,6 +109,11 @@ face_tangents_kernel(rnr_mesh mesh, float* __restrict__ out) {
     const float3 tn = normalize3(f3(f * (d2y * e1.x - d1y * e2.x), f * (d2y * e1.y - d1y * e2.y),
                                     f * (d2y * e1.z - d1y * e2.z)));
     out[i * 3 + 0] = tn.x; out[i * 3 + 1] = tn.y; out[i * 3 + 2] = tn.z;
+}
+
+__global__ void __launch_bounds__(256)
+face_tangents_kernel(rnr_mesh mesh, float* __restrict__ out) {
+    face_tangent(blockIdx.x * blockDim.x + threadIdx.x, mesh, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -702,13 +719,11 @@ sh_basis_kernel(const float* __restrict__ dirs, float* __restrict__ out, int n, 
 // out[s,c] = sum_b basis[s,b] * coeff[b,c].  64 samples per workgroup: their basis rows are one contiguous block of
 // 64*nb floats, staged through LDS with coalesced loads (a lane-per-output version reads rows nb floats apart).
 constexpr int SHR_ROWS = 64;
-__global__ void __launch_bounds__(256)
-sh_reconstruct_kernel(const float* __restrict__ basis, const float* __restrict__ coeff, float* __restrict__ out,
-                      int ns, int nb, int nc) {
-    extern __shared__ float sh_lds[];              // [SHR_ROWS*nb] basis rows, then [nb*nc] coefficients
-    float* bl = sh_lds;
+__device__ __forceinline__ void sh_reconstruct_block(int block, float* sh_lds, const float* __restrict__ basis,
+                                                     const float* __restrict__ coeff, float* __restrict__ out, int ns, int nb, int nc) {
+    float* bl = sh_lds;                             // [SHR_ROWS*nb] basis rows, then [nb*nc] coefficients
     float* cl = sh_lds + SHR_ROWS * nb;
-    const int s0 = blockIdx.x * SHR_ROWS;
+    const int s0 = block * SHR_ROWS;
     const int rows = min(SHR_ROWS, ns - s0);
     for (int i = threadIdx.x; i < rows * nb; i += blockDim.x) bl[i] = basis[(size_t)s0 * nb + i];
     for (int i = threadIdx.x; i < nb * nc; i += blockDim.x) cl[i] = coeff[i];
@@ -718,6 +733,47 @@ sh_reconstruct_kernel(const float* __restrict__ basis, const float* __restrict__
         float acc = 0.f;
         for (int b = 0; b < nb; b++) acc += bl[s * nb + b] * cl[b * nc + c];
         out[(size_t)(s0 + s) * nc + c] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sh_reconstruct_kernel(const float* __restrict__ basis, const float* __restrict__ coeff, float* __restrict__ out,
+                      int ns, int nb, int nc) {
+    extern __shared__ float sh_lds[];
+    sh_reconstruct_block(blockIdx.x, sh_lds, basis, coeff, out, ns, nb, nc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rnr_frame_prepare: the per-call preliminaries of a frame batch in ONE launch (r04; at one view per call they were six
+// launches of ~5 us each in front of a 2.5 ms frame): block ranges of one grid run
+//   [0, b_proj)            vertex projection straight from the [N,4,4] poses (no R / t copies);
+//   [b_proj, b_tan)        per-face tangents, recomputed per call as render.get_TBN_map does (render.py:135-150);
+//   [b_tan, b_lp)          the light probe reconstructed from SH coefficients (LightingSH.reconstruct_lp, network.py:622-627);
+//   [b_lp, b_clear)        the per-call clearing of the rasterizer workspace (tile counters 0, depth keys ~0).
+// The parts are independent of each other; each runs the code of its stand-alone kernel (same bits).
+struct FramePrepParams {
+    rnr_mesh mesh;
+    const float* K; const float* pose; float* v_uvz; int nviews; float orig_size, eps;
+    float* tangents;
+    const float* lp_basis; const float* lp_coeff; float* lp_out; int lp_ns, lp_nb, lp_nc;
+    uint4* counters; long counter_vec; uint4* keys; long key_vec;
+    int b_proj, b_tan, b_lp, b_clear;
+};
+__global__ void __launch_bounds__(256)
+frame_prepare_kernel(const FramePrepParams P) {
+    extern __shared__ float sh_lds[];
+    const int b = blockIdx.x;
+    if (b < P.b_proj) {
+        project_vertex<true>((long)b * 256 + threadIdx.x, P.mesh.v, P.K, P.pose, nullptr, nullptr, nullptr, nullptr, P.v_uvz,
+                             P.nviews, P.mesh.num_vertices, P.orig_size, P.eps);
+    } else if (b < P.b_tan) {
+        face_tangent((b - P.b_proj) * 256 + threadIdx.x, P.mesh, P.tangents);
+    } else if (b < P.b_lp) {
+        sh_reconstruct_block(b - P.b_tan, sh_lds, P.lp_basis, P.lp_coeff, P.lp_out, P.lp_ns, P.lp_nb, P.lp_nc);
+    } else {
+        const long i = (long)(b - P.b_lp) * 256 + threadIdx.x;
+        if (i < P.counter_vec) P.counters[i] = make_uint4(0u, 0u, 0u, 0u);
+        else if (i - P.counter_vec < P.key_vec) P.keys[i - P.counter_vec] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
 }
 
@@ -1085,6 +1141,44 @@ extern "C" int rnr_sh_reconstruct(const float* basis, const float* coeff, float*
     hipLaunchKernelGGL(sh_reconstruct_kernel, dim3((unsigned)((num_samples + SHR_ROWS - 1) / SHR_ROWS)), dim3(256), lds,
                        as_stream(stream), basis, coeff, out, num_samples, num_basis, num_channels);
     return check_launch("sh_reconstruct_kernel");
+}
+
+extern "C" int rnr_frame_prepare(const rnr_mesh* mesh, const float* K, const float* pose, int num_views, int image_size,
+                                 float eps, float* v_uvz, float* tangents, const float* lp_basis, const float* lp_coeff,
+                                 float* light_probe, int lp_samples, int lp_num_basis, int lp_channels,
+                                 void* gbuffer_workspace, void* stream) {
+    RNR_REQUIRE(mesh && mesh->v && mesh->num_vertices > 0 && mesh->num_faces > 0, "rnr_frame_prepare: incomplete mesh");
+    RNR_REQUIRE(num_views > 0 && image_size > 0, "rnr_frame_prepare: bad sizes");
+    RNR_REQUIRE(!v_uvz || (K && pose), "rnr_frame_prepare: the projection needs K and pose");
+    RNR_REQUIRE(!tangents || (mesh->vt && mesh->f_v_idx && mesh->f_vt_idx), "rnr_frame_prepare: tangents need vt and the index arrays");
+    RNR_REQUIRE(!light_probe || (lp_basis && lp_coeff && lp_samples > 0 && lp_num_basis > 0 && lp_channels > 0),
+                "rnr_frame_prepare: the light probe needs basis, coefficients and sizes");
+    FramePrepParams P = {};
+    P.mesh = *mesh; P.K = K; P.pose = pose; P.v_uvz = v_uvz; P.nviews = num_views; P.orig_size = (float)image_size; P.eps = eps;
+    P.tangents = tangents;
+    P.lp_basis = lp_basis; P.lp_coeff = lp_coeff; P.lp_out = light_probe; P.lp_ns = lp_samples; P.lp_nb = lp_num_basis;
+    P.lp_nc = lp_channels;
+    size_t lds = 0;
+    long nb = 0;
+    if (v_uvz) nb += ((long)num_views * mesh->num_vertices + 255) / 256;
+    P.b_proj = (int)nb;
+    if (tangents) nb += (mesh->num_faces + 255) / 256;
+    P.b_tan = (int)nb;
+    if (light_probe) {
+        lds = (size_t)(SHR_ROWS * lp_num_basis + lp_num_basis * lp_channels) * sizeof(float);
+        RNR_REQUIRE(lds <= 64 * 1024, "rnr_frame_prepare: num_basis * (64 + num_channels) floats must fit 64 KiB of LDS");
+        nb += (lp_samples + SHR_ROWS - 1) / SHR_ROWS;
+    }
+    P.b_lp = (int)nb;
+    if (gbuffer_workspace) {
+        gbuffer_clear_regions(gbuffer_workspace, num_views, mesh->num_faces, image_size, &P.counters, &P.counter_vec, &P.keys,
+                              &P.key_vec);
+        nb += (P.counter_vec + P.key_vec + 255) / 256;
+    }
+    P.b_clear = (int)nb;
+    RNR_REQUIRE(nb > 0 && nb < (1L << 31), "rnr_frame_prepare: nothing to do / grid too large");
+    hipLaunchKernelGGL(frame_prepare_kernel, dim3((unsigned)nb), dim3(256), lds, as_stream(stream), P);
+    return check_launch("frame_prepare_kernel");
 }
 
 extern "C" int rnr_sh_fit(const float* samples, const float* basis, float* out, int num_samples, int num_basis,

@@ -74,6 +74,10 @@ SIGNATURES = {
     'rnr_gbuffer_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'rnr_rasterize_gbuffer': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_float, P(RnrGbuffer),
                                       c_void_p, c_void_p]),
+    'rnr_rasterize_gbuffer_prepared': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_float, P(RnrGbuffer),
+                                               c_void_p, c_void_p]),
+    'rnr_frame_prepare': (c_int, [P(RnrMesh), c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rnr_face_tangents': (c_int, [P(RnrMesh), c_void_p, c_void_p]),
     'rnr_shade_inputs': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, P(c_void_p), P(c_int), c_int, c_int,
                                                   c_int, P(RnrRays), c_void_p, c_int, c_void_p, c_void_p, c_void_p,

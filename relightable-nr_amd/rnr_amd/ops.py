@@ -270,8 +270,9 @@ GBUFFER_MAPS = {'face_index_map': (torch.int32, ()), 'alpha': (torch.float32, ()
 
 
 @_device_op
-def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=None, out=None, workspace=None):
-    """network.Rasterizer.forward's per-pixel maps in one pass.  Returns dict name -> tensor [N,S,S(,k)]."""
+def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=None, out=None, workspace=None, prepared=False):
+    """network.Rasterizer.forward's per-pixel maps in one pass.  Returns dict name -> tensor [N,S,S(,k)].
+    prepared: `workspace` was cleared by frame_prepare on this stream for exactly this call (one launch fewer)."""
     L = _lib.load()
     _chk(v_uvz, 'v_uvz')
     N, S = v_uvz.shape[0], int(image_size)
@@ -286,14 +287,45 @@ def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=Non
         _chk(pose, 'pose')
     if workspace is None:
         workspace = torch.empty(L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces, S), dtype=torch.uint8, device=v_uvz.device)
-    check(L.rnr_rasterize_gbuffer(ctypes.byref(mesh.c), _ptr(v_uvz), _ptr(pose), N, S, float(near), float(far),
-                                  ctypes.byref(gb), _ptr(workspace), _stream()))
+    if prepared and workspace is None:
+        raise ValueError('rasterize_gbuffer(prepared=True) needs the workspace frame_prepare cleared')
+    fn = L.rnr_rasterize_gbuffer_prepared if prepared else L.rnr_rasterize_gbuffer
+    check(fn(ctypes.byref(mesh.c), _ptr(v_uvz), _ptr(pose), N, S, float(near), float(far), ctypes.byref(gb), _ptr(workspace),
+             _stream()))
     return out
 
 
 @_device_op
+def frame_prepare(mesh, K, pose, image_size, v_uvz=None, tangents=None, lp_basis=None, lp_coeff=None, light_probe=None,
+                  workspace=None, eps=1e-9):
+    """The per-call preliminaries of a frame batch in one launch (rnr_frame_prepare): vertex projection straight from the
+    [N,4,4] poses into v_uvz [N,nv,3], per-face tangents [nf,3], the light probe [ns,nc] = lp_basis [ns,nb] @ lp_coeff [nb,nc],
+    and the clearing of a rasterize_gbuffer workspace.  Outputs are caller-allocated; None skips a part."""
+    L = _lib.load()
+    _chk(K, 'K'); _chk(pose, 'pose')
+    N = K.shape[0]
+    for x, n in ((v_uvz, 'v_uvz'), (tangents, 'tangents'), (lp_basis, 'lp_basis'), (lp_coeff, 'lp_coeff'), (light_probe, 'light_probe')):
+        if x is not None:
+            _chk(x, n)
+    if v_uvz is not None and tuple(v_uvz.shape) != (N, mesh.num_vertices, 3):
+        raise ValueError('v_uvz must be [%d, %d, 3]' % (N, mesh.num_vertices))
+    if tangents is not None and tuple(tangents.shape) != (mesh.num_faces, 3):
+        raise ValueError('tangents must be [%d, 3]' % mesh.num_faces)
+    ns = nb = nc = 0
+    if light_probe is not None:
+        ns, nb = lp_basis.shape
+        nc = lp_coeff.shape[1]
+        if lp_coeff.shape[0] != nb or light_probe.numel() != ns * nc:
+            raise ValueError('light_probe must hold lp_basis [%d,%d] @ lp_coeff [%d,%d]' % (ns, nb, lp_coeff.shape[0], nc))
+    if workspace is not None and workspace.numel() < L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces, int(image_size)):
+        raise ValueError('workspace smaller than rnr_gbuffer_workspace_bytes(%d views)' % N)
+    check(L.rnr_frame_prepare(ctypes.byref(mesh.c), _ptr(K), _ptr(pose), N, int(image_size), float(eps), _ptr(v_uvz), _ptr(tangents),
+                              _ptr(lp_basis), _ptr(lp_coeff), _ptr(light_probe), int(ns), int(nb), int(nc), _ptr(workspace), _stream()))
+
+
+@_device_op
 def shade_inputs(gb, mesh, proj_inv, R_inv, textures, pivots_spec, pivots_diff, sh_start_ch, c_pad=None,
-                 want_rays_uv=False, want_neural_img=False, want_sh=False, net_in=None):
+                 want_rays_uv=False, want_neural_img=False, want_sh=False, net_in=None, tangents=None):
     """G-buffer -> channel-last RenderingNet input [N,H,W,c_pad] (+ optional API copies).
     textures: list of [1,S_l,S_l,C] or [S_l,S_l,C] device tensors; pivots_*: [3,R] CPU float tensors."""
     L = _lib.load()
@@ -317,7 +349,7 @@ def shade_inputs(gb, mesh, proj_inv, R_inv, textures, pivots_spec, pivots_diff, 
     pd = pivots_diff.detach().cpu().contiguous().float()
     rays = RnrRays(ps.data_ptr(), pd.data_ptr(), ns, nd)
     check(L.rnr_shade_inputs(_ptr(_chk(fim, 'face_index_map', torch.int32)), _ptr(_chk(alpha, 'alpha')),
-                             _ptr(_chk(uv, 'uv_map')), _ptr(_chk(nrm, 'normal_map')), _ptr(mesh.tangents()),
+                             _ptr(_chk(uv, 'uv_map')), _ptr(_chk(nrm, 'normal_map')), _ptr(mesh.tangents() if tangents is None else _chk(tangents, 'tangents')),
                              mesh.num_faces, _ptr(_chk(proj_inv, 'proj_inv')), _ptr(_chk(R_inv, 'R_inv')), tex_ptrs,
                              tex_sizes, nl, C, int(sh_start_ch), ctypes.byref(rays), _ptr(net_in), c_pad,
                              _ptr(rays_uv), _ptr(neural), _ptr(sh), N, H, W, _stream()))

@@ -140,6 +140,19 @@ class RNRPipeline:
             sl.flip = 0
             self._slots.append(sl)
 
+    def _prep(self, slot):
+        """Outputs of ops.frame_prepare private to the pipeline's own call state or to a slot in flight: projected vertices
+        [max_views, nv, 3], per-face tangents [nf, 3] and (with SH lighting) the reconstructed light probe [h, w, 3]."""
+        owner = self if slot is None else slot
+        b = getattr(owner, '_prep_buf', None)
+        if b is None:
+            b = {'v_uvz': torch.empty(self.max_views, self.mesh.num_vertices, 3, dtype=torch.float32, device=self.dev),
+                 'tangents': torch.empty(self.mesh.num_faces, 3, dtype=torch.float32, device=self.dev),
+                 'lp': None if self.sh_lighting is None else
+                 torch.empty(self.sh_lighting.h, self.sh_lighting.w, 3, dtype=torch.float32, device=self.dev)}
+            owner._prep_buf = b
+        return b
+
     def _ray_w(self, slot, lane):
         """[max_views,S,S,c_out_pad] ray-weight buffer of the pipeline (shared by the view-group lanes, which use disjoint
         view ranges) or of a slot."""
@@ -187,11 +200,9 @@ class RNRPipeline:
             self._next_slot = (self._next_slot + 1) % len(self._slots)
             sl.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(sl.stream):
-                # per-call work of the reference inside the slot's stream too (tangents, SH light probe): every temporary
-                # is allocated, used and recycled in that stream's order
-                self.mesh._tangents = None
-                self.mesh.tangents()
-                lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
+                # per-call work of the reference inside the slot's stream too (tangents, SH light probe, projection): one
+                # launch (ops.frame_prepare inside _render_group), outputs private to the slot
+                lp = self.lp if self.sh_lighting is None else ('sh', lighting_idx)
                 image = sl.images[sl.flip][:N]
                 sl.flip ^= 1
                 args = [t.contiguous() for t in (proj, pose, proj_inv, R_inv)]
@@ -199,7 +210,7 @@ class RNRPipeline:
                     # the caller's tensors are read by kernels of THIS stream: tell the caching allocator, or a caller that
                     # drops its pose tensors right after submit() gets their memory recycled under the running kernels
                     t.record_stream(sl.stream)
-                self._render_group(0, 0, N, *args, lp, image, lambda name: None, slot=sl)
+                self._render_group(0, 0, N, *args, lp, image, lambda name: None, slot=sl, fused=True)
                 ev = torch.cuda.Event()
                 ev.record(sl.stream)
             return FrameHandle(image, ev)
@@ -216,17 +227,23 @@ class RNRPipeline:
         if N > self.max_views:
             raise RuntimeError('pipeline built for max_views=%d, got %d poses' % (self.max_views, N))
         proj, pose, proj_inv, R_inv = proj.contiguous(), pose.contiguous(), proj_inv.contiguous(), R_inv.contiguous()
-        self.mesh._tangents = None          # per-face tangents recomputed per call, as get_TBN_map does (render.py:135-150)
-        self.mesh.tangents()
-        lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
         image = self._images[self._flip][:N]
         self._flip ^= 1
         lanes = 1 if (stage_events is not None or keep_intermediates or self._v_uvz_override is not None) else min(self.n_streams, N)
+        fused = lanes == 1 and self._v_uvz_override is None
+        if fused:
+            # per-face tangents (recomputed per call, as get_TBN_map does, render.py:135-150), the light probe and the vertex
+            # projection share one launch with the rasterizer's workspace clearing: ops.frame_prepare in _render_group
+            lp = self.lp if self.sh_lighting is None else ('sh', lighting_idx)
+        else:
+            self.mesh._tangents = None
+            self.mesh.tangents()
+            lp = self.lp if self.sh_lighting is None else self.sh_lighting.light_probe(self.sh_coeff[lighting_idx])
         if lanes == 1:
             if N > self._lane_unets[0].N:
                 raise RuntimeError('pipeline built with streams=%d: a single-stream call takes at most %d poses'
                                    % (self.n_streams, self._lane_unets[0].N))
-            inter = self._render_group(0, 0, N, proj, pose, proj_inv, R_inv, lp, image, mark)
+            inter = self._render_group(0, 0, N, proj, pose, proj_inv, R_inv, lp, image, mark, fused=fused)
             if keep_intermediates:
                 self.last = inter
             return image
@@ -245,23 +262,40 @@ class RNRPipeline:
             cur.wait_stream(st)
         return image
 
-    def _render_group(self, lane, lo, hi, proj, pose, proj_inv, R_inv, lp, image, mark, slot=None):
+    def _render_group(self, lane, lo, hi, proj, pose, proj_inv, R_inv, lp, image, mark, slot=None, fused=False):
         """Views [lo, hi) of the batch on the current stream, with lane-private scratch and U-Net activations (or, for a
         submitted call, everything private to its slot)."""
         n = hi - lo
         unet = self._lane_unets[lane] if slot is None else slot.unet
         gbufs = self._gb if slot is None else slot.gb
         net_in = self._net_in if slot is None else slot.net_in
-        R = pose[lo:hi, :3, :3].contiguous()
-        t = pose[lo:hi, :3, 3].contiguous()
         ov = getattr(self, '_v_uvz_override', None) if slot is None else None
-        v_uvz = ops.project_vertices(self.mesh.v, proj[lo:hi], R, t, self.S) if ov is None else ov[lo:hi].contiguous()
         gb = {m: gbufs[m][lo:hi] for m in self._gb_maps}
-        ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb,
-                              workspace=self._lane_ws[lane] if slot is None else slot.ws)
+        ws = self._lane_ws[lane] if slot is None else slot.ws
+        fused_prepare = fused and ov is None
+        if fused_prepare:
+            pb = self._prep(slot)
+            sh_lp = isinstance(lp, tuple)
+            ops.frame_prepare(self.mesh, proj[lo:hi], pose[lo:hi], self.S, v_uvz=pb['v_uvz'][:n], tangents=pb['tangents'],
+                              lp_basis=self.sh_lighting.basis_recon if sh_lp else None,
+                              lp_coeff=self.sh_coeff[lp[1]] if sh_lp else None, light_probe=pb['lp'] if sh_lp else None,
+                              workspace=ws)
+            v_uvz, tangents = pb['v_uvz'][:n], pb['tangents']
+            if sh_lp:
+                lp = pb['lp']
+            ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb, workspace=ws,
+                                  prepared=True)
+        else:
+            if ov is None:
+                v_uvz = ops.project_vertices(self.mesh.v, proj[lo:hi], pose[lo:hi, :3, :3].contiguous(),
+                                             pose[lo:hi, :3, 3].contiguous(), self.S)
+            else:
+                v_uvz = ov[lo:hi].contiguous()
+            tangents = None             # mesh.tangents(): computed by the caller for this call
+            ops.rasterize_gbuffer(self.mesh, v_uvz, None, self.S, self.near, self.far, maps=self._gb_maps, out=gb, workspace=ws)
         mark('raster')
         sh = ops.shade_inputs(gb, self.mesh, proj_inv[lo:hi], R_inv[lo:hi], self.textures, self.pivots_spec,
-                              self.pivots_diff, self.sh_start_ch, c_pad=unet.in_c_pad, net_in=net_in[lo:hi])
+                              self.pivots_diff, self.sh_start_ch, c_pad=unet.in_c_pad, net_in=net_in[lo:hi], tangents=tangents)
         mark('shade_inputs')
         if self.fuse_ray:
             ray_w = ops.ray_weights(sh['net_in'], gb['alpha'], lp, self.n_spec, self.n_diff, unet.out.c_pad, albedo_diff_ch=0,

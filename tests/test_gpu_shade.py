@@ -169,3 +169,44 @@ def test_lighting_front_end_vs_oracle():
     ref_lp = orc.reconstruct_lp(ref_coeff, torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32)))
     assert lp.shape == (100, 200, 3)
     assert torch.allclose(lp.cpu(), ref_lp, atol=5e-4)
+
+
+@pytest.mark.parametrize('n_views', [1, 3])
+def test_frame_prepare_equals_the_separate_launches(n_views):
+    """rnr_frame_prepare (r04: projection from the [N,4,4] poses + per-face tangents + SH light probe + workspace clearing in
+    ONE launch) against the stand-alone entry points: every output bit-identical, and rnr_rasterize_gbuffer_prepared on the
+    workspace it cleared gives the maps of rnr_rasterize_gbuffer — also when the workspace is dirty from a previous call
+    with another view count (the layout depends on it)."""
+    from rnr_amd import ops, scene
+    from rnr_amd.lighting import SHLighting
+    S = 128
+    m = scene.uv_sphere(24, 48)
+    mesh = ops.DeviceMesh(m['v'], m['vt'], m['vn'], m['f_v_idx'], m['f_vt_idx'], m['f_vn_idx'], DEV)
+    views = {k: torch.from_numpy(v).to(DEV) for k, v in scene.spiral_views(S, [5, 300, 650][:n_views]).items()}
+    K, pose = views['proj'].contiguous(), views['pose'].contiguous()
+    shl = SHLighting(10, torch.device(DEV))
+    coeff = torch.from_numpy(scene.synthetic_sh_coeff(2, 10, 1)).to(DEV)[1].contiguous()
+    # separate launches
+    v_ref = ops.project_vertices(mesh.v, K, pose[:, :3, :3].contiguous(), pose[:, :3, 3].contiguous(), S)
+    t_ref = mesh.tangents().clone()
+    lp_ref = shl.light_probe(coeff)
+    maps = ['face_index_map', 'alpha', 'uv_map', 'normal_map']
+    gb_ref = ops.rasterize_gbuffer(mesh, v_ref, None, S, maps=maps)
+    # one launch
+    L = ops._lib.load()
+    ws = torch.full((L.rnr_gbuffer_workspace_bytes(3, mesh.num_faces, S),), 0x5A, dtype=torch.uint8, device=DEV)   # dirty, sized for 3 views
+    v = torch.empty(n_views, mesh.num_vertices, 3, device=DEV)
+    t = torch.empty(mesh.num_faces, 3, device=DEV)
+    lp = torch.empty(shl.h, shl.w, 3, device=DEV)
+    ops.frame_prepare(mesh, K, pose, S, v_uvz=v, tangents=t, lp_basis=shl.basis_recon, lp_coeff=coeff, light_probe=lp, workspace=ws)
+    assert torch.equal(v, v_ref) and torch.equal(t, t_ref) and torch.equal(lp.reshape(lp_ref.shape), lp_ref)
+    gb = ops.rasterize_gbuffer(mesh, v, None, S, maps=maps, workspace=ws, prepared=True)
+    for k in maps:
+        assert torch.equal(gb[k], gb_ref[k]), k
+    assert int((gb['face_index_map'] >= 0).sum()) > 1000
+    # parts are optional: projection only
+    v2 = torch.zeros_like(v)
+    ops.frame_prepare(mesh, K, pose, S, v_uvz=v2)
+    assert torch.equal(v2, v_ref)
+    with pytest.raises(ValueError):
+        ops.frame_prepare(mesh, K, pose, S, v_uvz=v[:, :-1].contiguous())
