@@ -1,9 +1,10 @@
 """ISA statistics of one kernel of conv.hip (cross-compiled here, no GPU): instruction mix, registers, spills, LDS.
-Usage: python scripts/isa_stats.py KERNEL_SUBSTRING [extra hipcc flags ...]   e.g. conv_wino_kernel"""
+Usage: python scripts/isa_stats.py KERNEL_SUBSTRING [FILE.hip] [extra hipcc flags ...]   e.g. conv_wino_kernel, or shade_inputs_kernel shade.hip"""
 import re, subprocess, sys, collections, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name = sys.argv[1]
-src = os.path.join(ROOT, 'relightable-nr_amd', 'csrc', 'conv.hip' if 'conv' in name or len(sys.argv) < 3 or not sys.argv[2].endswith('.hip') else sys.argv[2])
+hips = [f for f in sys.argv[2:] if f.endswith('.hip')]
+src = os.path.join(ROOT, 'relightable-nr_amd', 'csrc', os.path.basename(hips[0]) if hips else 'conv.hip')
 flags = [f for f in sys.argv[2:] if not f.endswith('.hip')]
 out = '/tmp/isa_%d.s' % os.getpid()
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-fno-slp-vectorize'] if src.endswith('conv.hip') else ['-ffp-contract=off']) + flags + ['-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)

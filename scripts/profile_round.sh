@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage (GPU box, from the repo root): scripts/profile_round.sh TAG      e.g. TAG=r03
+# usage (GPU box, from the repo root): scripts/profile_round.sh TAG      e.g. TAG=r04
 # Collects everything profiles/ holds for a round into gpurun_out/profile_TAG/:
 #   kernel-trace statistics of the bench loop (8 views per step and 1 view per step = the reference's calling mode, product path =
 #   Winograd convolutions; 8 views per step with direct convolutions and with the two emulated precisions), the PMC passes
 #   (separate runs per counter group, never combined with other trace domains) of the product path at both batch sizes,
 #   per-layer timing tables (both algorithms), the accuracy tables of the Winograd and emulation kernels, and the bench line
 #   itself (roofline.traffic taken from THIS run's PMC files, for the headline and for single_view_mode).
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT

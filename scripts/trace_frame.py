@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'project_vertices' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'frame_prepare' in r['Kernel_Name'] or 'project_vertices' in r['Kernel_Name']]     # first launch of a frame
 s, e = idx[-2], idx[-1]
 t0 = int(rows[s]['Start_Timestamp'])
 tot = {}
