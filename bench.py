@@ -53,7 +53,7 @@ def parse(argv=None):
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6', 'f16x3'],
                     help="conv arithmetic of the timed loop: exact fp32 MFMA (default, the headline) or fp32 emulated on the bf16 "
                          "matrix cores (RNR_CONV_F32_EMU_BF16X6)")
-    ap.add_argument('--conv-algo', default=None, choices=['winograd', 'direct'],
+    ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd4', 'direct'],
                     help='U-Net convolution algorithm (rnr_amd.unet.UNetPlan conv_algo; default: the library default, winograd — '
                          'fp32 Winograd F(2x2,3x3) / F(2x2,2x2) on the f32 MFMA; direct = every layer as a direct implicit GEMM)')
     ap.add_argument('--pmc-file', default=None,
@@ -300,7 +300,8 @@ def algo_block(unet, n_views, stage_ms, peak, masked_out_layer, direct_tf=None, 
         algos[-1] = 0
     blk = {'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
            'conv_algo': unet.conv_algo,
-           'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1) + algos.count(3), algos.count(2)],
+           'layers_direct_winograd3x3_winograd2x2': [algos.count(0), algos.count(1) + algos.count(3) + algos.count(4), algos.count(2)],
+           'layers_winograd_f4x4_3x3': algos.count(4),
            'executed_mfma_flops': ex}
     pmc = pmc_mfma_flops_per_step(traffic_info or {})
     blk['executed_flops_from_pmc'] = pmc
@@ -698,7 +699,7 @@ def main(argv=None):
                                                        'ms_per_step': dt2 / args.steps * 1e3,
                                                        'note': 'RNRPipeline(streams=2, skip_background_tiles=True); not the headline value'}
                 del pipe2
-        if extras and not fast and world == 1 and args.precision == 'f32' and pipe.unet.conv_algo == 'winograd':
+        if extras and not fast and world == 1 and args.precision == 'f32' and pipe.unet.conv_algo != 'direct':
             # every convolution as a direct implicit GEMM (the r01 - r03 path: conv_halo_kernel only), same frames to fp32 rounding
             try:
                 pd = make_pipeline(sc, args, dev, V, conv_algo='direct')

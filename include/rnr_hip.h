@@ -291,6 +291,13 @@ typedef struct rnr_conv_desc {
  * neighbouring pixels, so an inf / NaN activation reaches every output of the 2 x 2 tiles whose patch contains it (a direct
  * convolution confines it to the outputs whose window contains it). */
 #define RNR_CONV_WINOGRAD 8
+/* (with RNR_CONV_WINOGRAD) F(4x4, 3x3) for the 3x3 convolutions whose maps tile into 32 x 16 pixels, whose columns into 64s and
+ * whose grid fills the chip: 36 multiplications per 4 x 4 outputs (2.25 per output; F(2x2, 3x3): 4, direct: 9) on the
+ * interpolation points (0, +-3/4, +-3/2, inf).  Opt-in: the larger transforms (coefficients up to 3.375) put the rounding
+ * error at ~4.5 x the direct form's (rms; F(2x2, 3x3): 1.3 x) — scripts/experiments/winograd_accuracy_study.py,
+ * tests/test_gpu_unet.py.  The F(4x4, 3x3) weight image is stored behind the F(2x2, 3x3) one (both flags when packing AND
+ * convolving); shapes it does not cover run F(2x2, 3x3) / direct from the same buffer.  rnr_conv_algorithm reports 4. */
+#define RNR_CONV_WINOGRAD4 16
 
 /* Floats in the packed weight of `d` ([taps][c_in0_pad + c_in1_pad][c_out_pad], x4 parity classes for convT). */
 size_t rnr_packed_weight_floats(const rnr_conv_desc* d);
@@ -300,7 +307,8 @@ int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* pac
 
 /* Which algorithm rnr_conv2d* runs for (desc, N, input H, input W): 0 = direct implicit GEMM, 1 = Winograd F(2x2, 3x3),
  * 3 = the same for the 80-column out layer (16 x 16 x 4 MFMA tiles), 2 = Winograd F(2x2, 2x2) (16 multiplications per 2 x 2
- * outputs instead of 36, resp. 9 instead of 16); -1 = bad arguments.  Non-zero only with RNR_CONV_WINOGRAD in desc->flags.
+ * outputs instead of 36, resp. 9 instead of 16), 4 = Winograd F(4x4, 3x3) (RNR_CONV_WINOGRAD4); -1 = bad arguments.
+ * Non-zero only with RNR_CONV_WINOGRAD in desc->flags.
  * Masked launches (tile_mask != NULL) run 0 unless the plan is 3; rnr_conv2d_ray always runs 0. */
 int rnr_conv_algorithm(const rnr_conv_desc* d, int num_views, int in_h, int in_w);
 

@@ -1712,6 +1712,7 @@ pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __res
 #include "conv_wino.inc"
 #include "conv_wino80.inc"
 #include "conv_wino2.inc"
+#include "conv_wino4.inc"
 
 // mask[tile] = any(alpha > 0) over the tw x th output pixels of the tile (tile order = the halo kernels' mt index)
 __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restrict__ alpha, uint8_t* __restrict__ mask, int H,
@@ -1730,7 +1731,7 @@ __global__ void __launch_bounds__(256) active_tile_kernel(const float* __restric
 
 struct ConvPlan {
     int halo;       // 1: conv3x3_halo_kernel (2-D pixel tiles), 0: conv_mfma_kernel (linear pixel tiles)
-    int wino;       // 3: conv_wino80_kernel (F(2x2, 3x3) for the 80-column out layer, 16 x 4 pixel tiles),
+    int wino;       // 4: conv_wino4_kernel (F(4x4, 3x3), 32 x 16 pixel tiles x 64 columns), 3: conv_wino80_kernel (F(2x2, 3x3) for the 80-column out layer, 16 x 4 pixel tiles),
                     // 1: conv_wino_kernel (Winograd F(2x2, 3x3), 16 x 8 pixel tiles x 64 columns), 2: conv_wino2_kernel (F(2x2, 2x2),
                     // the 4x4 stride-2 convolutions: 16 x 8 tiles of the GEMM row space x 128 (conv) / 64 (transposed) columns)
     int cfg;        // column config 0: 64, 1: 96 (gather) / 80 (halo) / 96 (emulation), 2: 128; rows = bm (64 ... 256)
@@ -1751,6 +1752,9 @@ __global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, l
 #endif
 #ifndef RNR_WINO2_MIN_WGS
 #define RNR_WINO2_MIN_WGS 200        // fewer workgroups (one per CU) than this: the direct kernels
+#endif
+#ifndef RNR_WINO4_MIN_WGS
+#define RNR_WINO4_MIN_WGS 256        // fewer 32 x 16 pixel x 64 column tiles than this (one 12-wave workgroup per CU): F(2x2, 3x3)
 #endif
 #ifndef RNR_WINO_MIN_WGS
 #define RNR_WINO_MIN_WGS 256         // fewer 16 x 8 pixel x 64 column tiles than this: the direct kernels (they split K)
@@ -1902,6 +1906,19 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
             p->splitk = sk;
         }
     }
+    // F(4x4, 3x3) (opt-in, RNR_CONV_WINOGRAD4): 32 x 16 pixel tiles x 64 columns, one 12-wave workgroup per CU — when the grid
+    // gives every CU a workgroup (no split-K form)
+    static const int min_wgs4 = [] { const char* e = getenv("RNR_WINO4_MIN_WGS"); return e ? atoi(e) : RNR_WINO4_MIN_WGS; }();
+    if ((d->flags & RNR_CONV_WINOGRAD) && (d->flags & RNR_CONV_WINOGRAD4) && d->kind == RNR_CONV3x3_REFLECT && H % W4_PH == 0 &&
+        W % W4_PW == 0 && d->c_out_pad % W4_BN == 0 && view_elems < (1L << 30)) {
+        const long wgs = (long)N * (H / W4_PH) * (W / W4_PW) * (d->c_out_pad / W4_BN);
+        if (wgs >= min_wgs4) {
+            p->wino = 4; p->halo = 1; p->cfg = 0; p->tw = W4_PW; p->bm = W4_PW * W4_PH; p->bn = W4_BN;
+            p->mtiles = N * (H / W4_PH) * (W / W4_PW);
+            p->ntiles = d->c_out_pad / W4_BN;
+            p->splitk = 1;
+        }
+    }
     // ... and the 80-column out layer on the 16 x 16 x 4 instruction: 16 x 4 pixel tiles x all 80 columns (conv_wino80_kernel)
     if ((d->flags & RNR_CONV_WINOGRAD) && d->kind == RNR_CONV3x3_REFLECT && d->c_out_pad == 80 && H % W80_PH == 0 &&
         W % W80_PW == 0 && view_elems < (1L << 30)) {
@@ -1977,8 +1994,10 @@ static int check_desc(const rnr_conv_desc* d, const char* who) {
                 "%s: c_in1 %d / pad %d", who, d->c_in1, d->c_in1_pad);
     RNR_REQUIRE(d->c_out > 0 && d->c_out_pad >= d->c_out && d->c_out_pad % BK == 0,
                 "%s: c_out %d / pad %d", who, d->c_out, d->c_out_pad);
-    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_ANY | RNR_CONV_WINOGRAD)) == 0, "%s: unknown flags 0x%x", who,
-                d->flags);
+    RNR_REQUIRE((d->flags & ~(RNR_CONV_STATS_PREZEROED | RNR_CONV_F32_EMU_ANY | RNR_CONV_WINOGRAD | RNR_CONV_WINOGRAD4)) == 0,
+                "%s: unknown flags 0x%x", who, d->flags);
+    RNR_REQUIRE(!(d->flags & RNR_CONV_WINOGRAD4) || (d->flags & RNR_CONV_WINOGRAD),
+                "%s: RNR_CONV_WINOGRAD4 goes with RNR_CONV_WINOGRAD (its fallback for the shapes it does not cover)", who);
     RNR_REQUIRE((d->flags & RNR_CONV_F32_EMU_ANY) != RNR_CONV_F32_EMU_ANY, "%s: choose ONE emulation format", who);
     RNR_REQUIRE(!(d->flags & RNR_CONV_WINOGRAD) || !(d->flags & RNR_CONV_F32_EMU_ANY),
                 "%s: RNR_CONV_WINOGRAD is an exact-fp32 algorithm, not combined with the emulation formats", who);
@@ -1999,6 +2018,13 @@ static size_t wino_weight_floats(const rnr_conv_desc* d) {       // 0: this conv
         return d->c_out_pad % 64 ? 0 : (size_t)(d->c_out_pad / 64) * (npairs + W2_BDIST) * w2_step_floats<2>();
     return d->c_out_pad % 128 ? 0 : (size_t)(d->c_out_pad / 128) * (4 * npairs + W2_BDIST) * w2_step_floats<1>();     // four phases
 }
+static size_t wino4_weight_floats(const rnr_conv_desc* d) {      // 0: this convolution has no F(4x4, 3x3) image
+    if (!(d->flags & RNR_CONV_WINOGRAD) || !(d->flags & RNR_CONV_WINOGRAD4) || d->kind != RNR_CONV3x3_REFLECT ||
+        d->c_out_pad % W4_BN || d->c_out_pad == 80)
+        return 0;
+    const size_t npairs = (size_t)(d->c_in0_pad + d->c_in1_pad) / 2;
+    return (size_t)(d->c_out_pad / W4_BN) * (npairs + W4_BDIST) * W4_STEP_FLOATS;
+}
 static size_t packed_f32_floats(const rnr_conv_desc* d) {
     const size_t taps = d->kind == RNR_CONV3x3_REFLECT ? 9 : 16;          // 16 = 4x4 taps, or 4 parity classes x 4 taps
     return taps * (size_t)(d->c_in0_pad + d->c_in1_pad) * (size_t)weight_row_stride(d->c_out_pad);
@@ -2010,8 +2036,8 @@ extern "C" size_t rnr_packed_weight_floats(const rnr_conv_desc* d) {
     // emulation image behind the fp32 image: 64-byte header + 3 bf16 terms (6 bytes) or 2 fp16 terms (4 bytes) per weight
     if (d->flags & RNR_CONV_F32_EMU_BF16X6) return f32 + EMU_HEADER_BYTES / 4 + (f32 * 6 + 3) / 4;
     if (d->flags & RNR_CONV_F32_EMU_F16X3) return f32 + EMU_HEADER_BYTES / 4 + f32;
-    // Winograd image behind the fp32 image: 16 planes instead of 9 taps
-    return f32 + wino_weight_floats(d);
+    // Winograd image behind the fp32 image: 16 planes instead of 9 taps (and, with RNR_CONV_WINOGRAD4, the 36-plane image behind it)
+    return f32 + wino_weight_floats(d) + wino4_weight_floats(d);
 }
 
 extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight, float* packed, void* stream) {
@@ -2048,7 +2074,13 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
         else
             hipLaunchKernelGGL(pack_weight_wino2_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
                                weight, packed + total, nw);
-        return check_launch("pack_weight_wino_kernel");
+        if (int e = check_launch("pack_weight_wino_kernel")) return e;
+        if (const long nw4 = (long)wino4_weight_floats(d)) {
+            hipLaunchKernelGGL(pack_weight_wino4_kernel, dim3((unsigned)((nw4 + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
+                               weight, packed + total + nw, nw4);
+            return check_launch("pack_weight_wino4_kernel");
+        }
+        return 0;
     }
     return 0;
 }
@@ -2260,7 +2292,11 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     else if (pl.wino) {
         P.weight_wino = weight_packed + packed_f32_floats(d);
         P.par_inner = 0;
-        if (pl.wino == 1) launch_wino(dim3((unsigned)grid_wgs), P, st);
+        if (pl.wino == 4) {
+            P.weight_wino = weight_packed + packed_f32_floats(d) + wino_weight_floats(d);
+            launch_wino4(dim3((unsigned)grid_wgs), P, st);
+        }
+        else if (pl.wino == 1) launch_wino(dim3((unsigned)grid_wgs), P, st);
         else if (pl.wino == 3) launch_wino80(dim3((unsigned)grid_wgs), P, st);
         else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
         else launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);

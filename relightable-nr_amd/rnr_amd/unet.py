@@ -52,8 +52,10 @@ class UNetPlan:
         MFMA cycles (include/rnr_hip.h, RNR_CONV_F32_EMU_BF16X6 / RNR_CONV_F32_EMU_F16X3).
         conv_algo 'winograd': the 3x3 convolutions run as Winograd F(2x2, 3x3) and the 4x4 stride-2 ones (both directions) as
         F(2x2, 2x2) — fp32 operands and accumulation on the same matrix-core instruction, 2.25x / 1.78x fewer multiplications
-        (include/rnr_hip.h, RNR_CONV_WINOGRAD; 'f32' only) — where the layer shape allows; 'direct': every convolution as a
-        direct implicit GEMM.  None: $RNR_CONV_ALGO, else DEFAULT_CONV_ALGO.
+        (include/rnr_hip.h, RNR_CONV_WINOGRAD; 'f32' only) — where the layer shape allows; 'winograd4' (opt-in): additionally
+        F(4x4, 3x3) — 4x fewer multiplications than the direct form, ~3.5x the rounding error of F(2x2, 3x3) — for the 3x3
+        layers whose grid fills the chip (RNR_CONV_WINOGRAD4); 'direct': every convolution as a direct implicit GEMM.
+        None: $RNR_CONV_ALGO, else DEFAULT_CONV_ALGO.
         share_weights_with: another UNetPlan of the same network whose packed weights / BN parameters are reused
         (activations, statistics and scratch stay private) — one plan per HIP stream of RNRPipeline."""
         if precision not in _lib.EMU_FLAGS:
@@ -72,8 +74,8 @@ class UNetPlan:
             conv_algo = share_weights_with.conv_algo
         if conv_algo is None:
             conv_algo = os.environ.get('RNR_CONV_ALGO') or DEFAULT_CONV_ALGO
-        if conv_algo not in ('direct', 'winograd'):
-            raise ValueError("conv_algo must be 'direct' or 'winograd'")
+        if conv_algo not in ('direct', 'winograd', 'winograd4'):
+            raise ValueError("conv_algo must be 'direct', 'winograd' or 'winograd4'")
         if precision != 'f32':
             conv_algo = 'direct'        # the emulation kernels have no Winograd form
         self.conv_algo = conv_algo
@@ -86,7 +88,7 @@ class UNetPlan:
         # confines it to the windows that contain it; include/rnr_hip.h, RNR_CONV_WINOGRAD).  check_finite=None (the default)
         # therefore checks the FIRST forward of a Winograd plan — input and output, one host synchronisation, once — and warns;
         # True checks every forward and raises; False never checks.
-        self.check_finite = 'first' if (check_finite is None and conv_algo == 'winograd') else bool(check_finite)
+        self.check_finite = 'first' if (check_finite is None and conv_algo != 'direct') else bool(check_finite)
         self.L = _lib.load()
         self.dev = device
         self.N = int(max_views)
@@ -112,8 +114,10 @@ class UNetPlan:
             s1 = srcs[1] if len(srcs) > 1 else None
             desc = RnrConvDesc(kind, s0.c, s0.c_pad, s1.c if s1 else 0, s1.c_pad if s1 else 0, c_out, _pad16(c_out))
             desc.flags |= _lib.EMU_FLAGS[precision]
-            if conv_algo == 'winograd':
+            if conv_algo != 'direct':
                 desc.flags |= _lib.CONV_WINOGRAD
+            if conv_algo == 'winograd4' and kind == CONV3x3_REFLECT:
+                desc.flags |= _lib.CONV_WINOGRAD4
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
                 if packed.numel() != self.L.rnr_packed_weight_floats(ctypes.byref(desc)):
@@ -213,7 +217,7 @@ class UNetPlan:
             algo = self.L.rnr_conv_algorithm(ctypes.byref(d), int(n_views), h, w)
             if masked_out_layer and i == len(self.steps) - 1 and algo != 3:
                 algo = 0
-            total += self._layer_flops(d, h, w) / {0: 1.0, 1: 36.0 / 16.0, 2: 16.0 / 9.0, 3: 36.0 / 16.0}[algo]
+            total += self._layer_flops(d, h, w) / {0: 1.0, 1: 36.0 / 16.0, 2: 16.0 / 9.0, 3: 36.0 / 16.0, 4: 4.0}[algo]
         return total
 
     @staticmethod

@@ -85,12 +85,14 @@ def main():
     ap.add_argument('--layers', default='')
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--winograd', action='store_true', help='RNR_CONV_WINOGRAD: F(2x2, 3x3) for the 3x3 layers it covers')
+    ap.add_argument('--winograd4', action='store_true', help='+ RNR_CONV_WINOGRAD4: F(4x4, 3x3) where the shape allows')
     ap.add_argument('--no-stats', action='store_true')
     ap.add_argument('--unfused', action='store_true', help='legacy rnr_conv2d (separate split-K reduce, no BatchNorm finalise)')
     ap.add_argument('--zero', default='', help="'w' zero weights, 'a' zero activations, 'wa' both: data-dependent power")
     a = ap.parse_args()
     L = _lib.load()
-    flags = _lib.EMU_FLAGS[a.precision] | (_lib.CONV_WINOGRAD if a.winograd else 0)
+    flags = (_lib.EMU_FLAGS[a.precision] | (_lib.CONV_WINOGRAD if (a.winograd or a.winograd4) else 0) |
+             (_lib.CONV_WINOGRAD4 if a.winograd4 else 0))
     peak = {'f32': 157.3e12, 'bf16x6': 2.5e15 / 6, 'f16x3': 2.5e15 / 3}[a.precision]
     want = [int(x) for x in a.layers.split(',')] if a.layers else [l[0] for l in LAYERS]
     tot_us = tot_fl = 0.0

@@ -100,3 +100,25 @@ def test_split_winograd_grids_have_no_empty_slice(kind, hw, cout):
         per = -(-chunks // sk)
         assert (sk - 1) * per < chunks and per >= 4, (chunks, sk, per)
     assert seen_split > 10
+
+
+def test_winograd_f4x4_plan_and_image_size():
+    """RNR_CONV_WINOGRAD4: the 36-plane image sits behind the F(2x2, 3x3) one (3x3 layers with 64 k columns only); the plan
+    takes F(4x4, 3x3) when the map tiles into 32 x 16 pixels and the grid gives every CU a workgroup, and falls back otherwise."""
+    L = _lib.load()
+    both = _lib.CONV_WINOGRAD | _lib.CONV_WINOGRAD4
+    for cins, c_out in (((128,), 128), ((64, 64), 64), ((108,), 64)):
+        ctot = sum(pad16(c) for c in cins)
+        w2 = L.rnr_packed_weight_floats(ctypes.byref(desc(0, cins, c_out, _lib.CONV_WINOGRAD)))
+        w4 = L.rnr_packed_weight_floats(ctypes.byref(desc(0, cins, c_out, both)))
+        assert w4 == w2 + (pad16(c_out) // 64) * (ctot // 2 + 1) * 4608
+    for kind, cins, c_out in ((0, (64, 64), 78), (1, (64,), 128), (2, (128, 128), 64)):
+        assert (L.rnr_packed_weight_floats(ctypes.byref(desc(kind, cins, c_out, both))) ==
+                L.rnr_packed_weight_floats(ctypes.byref(desc(kind, cins, c_out, _lib.CONV_WINOGRAD))))
+    d = desc(0, (128,), 128, both)
+    assert L.rnr_conv_algorithm(ctypes.byref(d), 8, 256, 256) == 4           # 128 tiles x 2 column tiles x 8 views
+    assert L.rnr_conv_algorithm(ctypes.byref(d), 1, 256, 256) == 4           # 256 workgroups: one per CU
+    assert L.rnr_conv_algorithm(ctypes.byref(d), 1, 128, 128) == 1           # 64 workgroups: F(2x2, 3x3) (256 of its tiles)
+    assert L.rnr_conv_algorithm(ctypes.byref(d), 8, 256, 240) == 1           # width not a multiple of 32
+    assert L.rnr_conv_algorithm(ctypes.byref(desc(0, (128,), 128, _lib.CONV_WINOGRAD)), 8, 256, 256) == 1
+    assert L.rnr_conv_workspace_bytes(ctypes.byref(d), 8, 256, 256) == 256   # never split over K

@@ -637,3 +637,57 @@ def test_winograd_plan_checks_its_first_call_for_non_finite_values():
         UNetPlan(sd, 30, 78, 64, 5, (256, 256), 1, dev, conv_algo='winograd', share_weights_with=d)
     with pytest.raises(ValueError):
         UNetPlan(sd, 30, 78, 64, 5, (256, 256), 1, dev, precision='f16x3', share_weights_with=d)
+
+
+WINO4_CASES = [
+    # N, H, W, [C per source], c_out, algorithm rnr_conv_algorithm must report with RNR_CONV_WINOGRAD | RNR_CONV_WINOGRAD4
+    # (the F(4x4, 3x3) plan needs >= 256 workgroups of 32 x 16 pixels x 64 columns)
+    (16, 64, 64, [64], 128, 4),         # 8 tiles per view x 2 column tiles x 16 views = 256 workgroups: reflection on all four borders
+    (8, 128, 128, [108], 64, 4),        # the input layer's channel count (7 chunks, 4 padding channels), one column tile
+    (16, 32, 32, [64, 64], 128, 1),     # 64 workgroups of F(4x4, 3x3): too few -> F(2x2, 3x3) from the same packed buffer (256 of its tiles)
+    (64, 16, 32, [256], 256, 4),        # map = exactly one 32 x 16 tile per view: every halo pixel reflected; 4 column tiles
+    (16, 64, 128, [32, 96], 64, 4),     # skip concat with unequal sources (2 + 6 chunks), non-square
+    (2, 128, 128, [64, 64], 78, 3),     # 80 columns: no F(4x4, 3x3) image, the out layer's F(2x2, 3x3) kernel
+    (4, 64, 72, [64], 64, 0),           # width not a multiple of 16: direct
+]
+
+
+@pytest.mark.parametrize('N,H,W,cins,c_out,algo', WINO4_CASES)
+def test_conv_winograd_f4x4_vs_torch(N, H, W, cins, c_out, algo):
+    """RNR_CONV_WINOGRAD4 (conv_wino4_kernel: F(4x4, 3x3) on the points 0, +-3/4, +-3/2, inf) through rnr_conv2d_fused against a
+    float64 torch convolution: output, BatchNorm scale / shift of the same launch, padding columns, sync buffer left at zero,
+    the algorithm the plan reports, and the fallback (F(2x2, 3x3) / direct from the same packed buffer) for the shapes it does
+    not cover.  Tolerance 1e-4 of the output peak (VERDICT r03 item 6's gate; measured ~1e-5)."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(4000 + H + W + c_out + N)
+    srcs = []
+    for j, C in enumerate(cins):
+        raw = torch.randn(N, C, H, W, generator=g)
+        sc = torch.rand(N, C, generator=g) + 0.5
+        sh = torch.randn(N, C, generator=g) * 0.3
+        srcs.append((raw, sc, sh, 1 if j == 0 else 2))
+    cin = sum(cins)
+    w = torch.randn(c_out, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    pad16 = lambda c: (c + 15) // 16 * 16
+    flags = _lib.CONV_WINOGRAD | _lib.CONV_WINOGRAD4
+    desc = _lib.RnrConvDesc(0, cins[0], pad16(cins[0]), cins[1] if len(cins) > 1 else 0, pad16(cins[1]) if len(cins) > 1 else 0,
+                            c_out, pad16(c_out), flags)
+    assert _lib.load().rnr_conv_algorithm(ctypes.byref(desc), N, H, W) == algo
+    gamma, beta = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
+    out, scale, shift, sync = run_conv_fused(0, srcs, w, c_out, N, H, W, gamma, beta, flags=flags, repeats=2)
+    ref = ref_conv(0, srcs, w).permute(0, 2, 3, 1)
+    got = out[..., :c_out].double()
+    assert torch.isfinite(out).all() and int(sync.to(torch.int32).abs().sum()) == 0
+    assert float(out[..., c_out:].abs().max() if out.shape[-1] > c_out else 0.0) == 0.0
+    peak = ref.abs().max()
+    err = (got - ref).abs().max()
+    assert err < (3e-5 if algo in (1, 3) else 1e-4) * peak, (err, peak)
+    mean = ref.mean(dim=(1, 2))
+    var = ref.var(dim=(1, 2), unbiased=False)
+    sc_ref = gamma.double()[None] / torch.sqrt(var + 1e-5)
+    sh_ref = beta.double()[None] - mean * sc_ref
+    assert torch.allclose(scale[:, :c_out].double(), sc_ref, rtol=5e-5, atol=1e-6)
+    assert torch.allclose(shift[:, :c_out].double(), sh_ref, rtol=5e-5, atol=5e-5)
+    # the flag without its companion is refused
+    with pytest.raises(RuntimeError, match='WINOGRAD4'):
+        run_conv_fused(0, srcs, w, c_out, N, H, W, gamma, beta, flags=_lib.CONV_WINOGRAD4)
