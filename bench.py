@@ -208,7 +208,7 @@ def pmc_traffic_per_step(args, views_per_step=None):
         if (meta['views_per_step'], meta['precision'], meta.get('img_size', 512)) != (V, args.precision, args.img_size):
             continue
         # profiles recorded before the Winograd kernels existed carry no conv_algo: they are the direct path's
-        algo = (args.conv_algo or 'winograd') if args.precision == 'f32' else 'direct'
+        algo = (args.conv_algo or os.environ.get('RNR_CONV_ALGO') or 'winograd4') if args.precision == 'f32' else 'direct'
         if meta.get('conv_algo', 'direct') != algo:
             continue
         steps = meta['steps'] + meta['warmup']
@@ -313,9 +313,10 @@ def algo_block(unet, n_views, stage_ms, peak, masked_out_layer, direct_tf=None, 
     blk['algo_note'] = ("achieved / frac = multiply-add FLOPs the matrix cores execute (padding columns / channels included: what "
                         "SQ_INSTS_MFMA counts, cross-checked by executed_flops_from_pmc = SUM SQ_INSTS_MFMA x 4096 | 2048 of the PMC "
                         "file named in traffic_source) / stage time / peak.  effective_tflops_direct_form = the ALGORITHMIC FLOPs of "
-                        "SURVEY 8(d) (direct-form convolutions) / the same time: with conv_algo 'winograd' the 3x3 layers execute 16 "
-                        "instead of 36 multiplications per 2x2 outputs and the 4x4 stride-2 / transposed ones 9 instead of 16 (fp32 "
-                        "operands, fp32 accumulation, same MFMA instruction), algorithmic_speedup = their ratio")
+                        "SURVEY 8(d) (direct-form convolutions) / the same time: the Winograd 3x3 layers execute 16 instead of 36 "
+                        "multiplications per 2x2 outputs (F(2x2,3x3)) or 36 instead of 144 per 4x4 outputs (F(4x4,3x3), conv_algo "
+                        "'winograd4') and the 4x4 stride-2 / transposed ones 9 instead of 16 (fp32 operands, fp32 accumulation, same "
+                        "MFMA instruction), algorithmic_speedup = their ratio")
     return blk
 
 
@@ -408,7 +409,7 @@ def single_view_block(sc, args, dev):
         'views_per_call': 1, 'views': n1,
         'workload': 'test_rnr.py:265-393: spiral_step720 views in order, one view per call, %dx%d, full HIP RenderingNet' % (args.img_size, args.img_size),
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
                                                   '64^2 -> 32^2 stride-2 layer; everywhere else the BatchNorm finalise and the split-K combine '
                                                   'happen inside the conv launch; HIP events bracket the U-Net stage of every call)',
                      **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
@@ -615,7 +616,7 @@ def main(argv=None):
                                                                    3 * sc['n_rays'], args.nf0),
                        'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world,
                        'conv_algo': None if stub else pipe.unet.conv_algo},
-            'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
+            'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_wino80_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
                          **algo8, 'traffic': traffic,
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
                          **{k: v for k, v in traffic_info.items() if k != 'traffic_path'},
@@ -720,6 +721,19 @@ def main(argv=None):
                 del pd
             except Exception as e:          # noqa: BLE001 - an extra must never fail the bench line
                 res['with_direct_convolutions'] = {'error': str(e)[:200]}
+        if extras and not fast and world == 1 and args.precision == 'f32' and pipe.unet.conv_algo == 'winograd4':
+            # the r03 product path: F(2x2, 3x3) / F(2x2, 2x2) only (no F(4x4, 3x3) layers)
+            try:
+                p2 = make_pipeline(sc, args, dev, V, conv_algo='winograd')
+                restore_2 = hook_unet_events(p2.unet, args.steps + 2)
+                dt2 = timed(p2)
+                ums2 = restore_2()
+                res['with_winograd_f2x2_only'] = {
+                    'frames_per_s': args.steps * V / dt2, 'ms_per_step': dt2 / args.steps * 1e3, 'unet_stage_ms_per_step': ums2,
+                    'note': "RNRPipeline(conv_algo='winograd'): the r03 product path, every Winograd layer F(2x2, .); not the headline value"}
+                del p2
+            except Exception as e:          # noqa: BLE001 - an extra must never fail the bench line
+                res['with_winograd_f2x2_only'] = {'error': str(e)[:200]}
         if extras and not fast and world == 1:
             # the same steps with two of them in flight (RNRPipeline(inflight=2).submit: private activations per slot, the
             # non-conv stages and kernel tails of one step run under the convolutions of the other); full compute, same frames

@@ -32,7 +32,7 @@ class _Act:
         self.shift = None
 
 
-DEFAULT_CONV_ALGO = 'winograd'
+DEFAULT_CONV_ALGO = 'winograd4'
 
 
 class UNetPlan:

@@ -2,7 +2,7 @@
 # usage: scripts/pmc.sh TAG "COUNTERS A B C" ["COUNTERS ..."]...   one rocprofv3 --pmc pass per counter group
 # (never combined with trace domains other than --kernel-trace); results merged by scripts/pmc_merge.py
 TAG=$1; shift
-export VIEWS=${VIEWS:-8} PRECISION=${PRECISION:-f32} PMC_STEPS=2 PMC_WARMUP=1 CONV_ALGO=${CONV_ALGO:-winograd}
+export VIEWS=${VIEWS:-8} PRECISION=${PRECISION:-f32} PMC_STEPS=2 PMC_WARMUP=1 CONV_ALGO=${CONV_ALGO:-winograd4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

@@ -1,2 +1,5 @@
-echo "== F(2x2,3x3)"; python scripts/layer_time.py --views 8 --winograd --layers 1,2,4,6,8,10,13,15,17,19,21 2>/dev/null | grep "^L\|^sum"
-echo "== F(4x4,3x3)"; python scripts/layer_time.py --views 8 --winograd4 --layers 1,2,4,6,8,10,13,15,17,19,21 2>/dev/null | grep "^L\|^sum"
+# usage (GPU box): bash scripts/w4_ab.sh VARIANT...   F(4x4,3x3) layer times of library variants (base = in-tree)
+for v in "$@"; do
+  if [ "$v" != "base" ]; then export RNR_HIP_LIB=$PWD/build_abl/librnr_$v.so; else unset RNR_HIP_LIB; fi
+  echo "== $v"; timeout 120 python scripts/layer_time.py --views ${VIEWS:-8} --winograd4 --layers ${LAYERS:-1,2,4,6,8} 2>&1 | grep "^L\|rror\|fault" | head -30
+done

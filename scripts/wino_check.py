@@ -1,7 +1,7 @@
 """Winograd kernels (F(2x2, 3x3) for the 3x3 layers, F(2x2, 2x2) for the 4x4 stride-2 ones) against the direct exact-fp32
 kernels and a float64 convolution on U-Net layer shapes
 (GPU box): max |difference| relative to the rms of the output, statistics / BatchNorm scale-shift difference.
-Usage: python scripts/wino_check.py [--views 2]"""
+Usage: python scripts/wino_check.py [--views 2] [--f4x4]"""
 import argparse
 import ctypes
 import os
@@ -47,10 +47,13 @@ def run(L, flags, kind, H, cins, cout, V, data, w, gamma, beta):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--views', type=int, default=2)
+    ap.add_argument('--f4x4', action='store_true', help='RNR_CONV_WINOGRAD | RNR_CONV_WINOGRAD4: F(4x4, 3x3) where the plan takes it (set RNR_WINO4_MIN_WGS=1 to force it)')
     a = ap.parse_args()
     L = _lib.load()
     torch.manual_seed(1)
     V = a.views
+    global WFLAGS
+    WFLAGS = _lib.CONV_WINOGRAD | (_lib.CONV_WINOGRAD4 if a.f4x4 else 0)
     for kind, H, cins, cout in [(0, 64, (64,), 64), (0, 128, (108,), 64), (0, 64, (128,), 128), (0, 32, (256,), 256),
                                 (0, 32, (512,), 512), (0, 64, (64, 64), 64), (0, 128, (64, 64), 78), (0, 64, (112,), 78), (0, 16, (512,), 512), (0, 48, (32,), 192),
                                 (2, 16, (512,), 512), (2, 32, (64, 64), 64), (2, 64, (128, 128), 64), (2, 32, (256, 256), 128),
@@ -70,7 +73,7 @@ def main():
         w = (torch.rand(shape, device=DEV) * 2 - 1) / (cin * k * k) ** 0.5
         gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV)
         o_d, sc_d, sh_d = run(L, 0, kind, H, cins, cout, V, data, w, gamma, beta)
-        o_w, sc_w, sh_w = run(L, _lib.CONV_WINOGRAD, kind, H, cins, cout, V, data, w, gamma, beta)
+        o_w, sc_w, sh_w = run(L, WFLAGS, kind, H, cins, cout, V, data, w, gamma, beta)
         # float64 reference
         xs = []
         for j, C in enumerate(cins):
@@ -94,7 +97,7 @@ def main():
         r_w = float((o_w[..., :cout].double() - ref).pow(2).mean().sqrt()) / rms
         pad_ok = bool((o_w[..., cout:] == 0).all()) if pad16(cout) > cout else True
         dsc = _lib.RnrConvDesc(kind, cins[0], pad16(cins[0]), cins[1] if len(cins) > 1 else 0, pad16(cins[1]) if len(cins) > 1 else 0,
-                               cout, pad16(cout), _lib.CONV_WINOGRAD)
+                               cout, pad16(cout), WFLAGS)
         algo = L.rnr_conv_algorithm(ctypes.byref(dsc), V, H, H)
         print('algo %d  kind %d %4d^2 %-9s -> %3d  V=%d  max err / rms: direct %.2e winograd %.2e   rms err / rms: direct %.2e winograd %.2e   '
               'scale diff %.1e shift diff %.1e  pad cols zero %s  finite %s' % (

@@ -63,9 +63,9 @@ def test_bench_single_view_block():
     assert r['bound'] == 'mfma' and 0.3 < r['frac'] < r['frac_of_sustained'] < 1.0 and r['peak'] == 157.3
     assert abs(r['achieved'] - r['executed_mfma_flops'] / (r['stage_ms_per_view'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
     assert abs(r['effective_tflops_direct_form'] - r['alg_flops_per_view'] / (r['stage_ms_per_view'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
-    assert r['conv_algo'] == 'winograd' and sum(r['layers_direct_winograd3x3_winograd2x2']) == 22
+    assert r['conv_algo'] == 'winograd4' and sum(r['layers_direct_winograd3x3_winograd2x2']) == 22 and r['layers_winograd_f4x4_3x3'] >= 4
     assert r['layers_direct_winograd3x3_winograd2x2'][1] >= 8 and r['layers_direct_winograd3x3_winograd2x2'][2] >= 3
-    assert r['executed_mfma_flops'] < r['alg_flops_per_view'] and 1.5 < r['algorithmic_speedup'] < 2.25
+    assert r['executed_mfma_flops'] < r['alg_flops_per_view'] and 1.5 < r['algorithmic_speedup'] < 4.0
     if r.get('executed_flops_from_pmc'):
         assert 0.95 < r['executed_flops_pmc_over_model'] < 1.05
     fly = sv['two_calls_in_flight']
