@@ -2141,7 +2141,7 @@ static void mask_plan(const rnr_conv_desc* d, int num_views, int in_h, int in_w,
     make_plan(d, num_views, in_h, in_w, pl);
     if (pl->wino && pl->wino != 3) {
         rnr_conv_desc dd = *d;
-        dd.flags &= ~RNR_CONV_WINOGRAD;
+        dd.flags &= ~(RNR_CONV_WINOGRAD | RNR_CONV_WINOGRAD4);
         make_plan(&dd, num_views, in_h, in_w, pl);
     }
 }
@@ -2191,7 +2191,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     make_plan(d, num_views, in_h, in_w, &pl);
     if (pl.wino && (g_ray.w || (tile_mask && pl.wino != 3))) {    // ray-epilogue / masked launches run on the direct kernels' tiles (the out layer's own Winograd kernel takes a mask)
         rnr_conv_desc dd = *d;
-        dd.flags &= ~RNR_CONV_WINOGRAD;
+        dd.flags &= ~(RNR_CONV_WINOGRAD | RNR_CONV_WINOGRAD4);
         make_plan(&dd, num_views, in_h, in_w, &pl);
     }
     if (g_ray.w) pl.splitk = 1;         // the ray-renderer epilogue needs the whole K sum in one workgroup (small maps would split)
@@ -2245,6 +2245,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
             // bn_finalize_shards_kernel); the others get the finalise as a launch of its own
             // (a separate finalise launch for the big Winograd grids too was measured: -0.5 % on seven layers at 8 views — the
             // ticket is not what the short-K layers lose)
+            // (conv_wino4_kernel, one 12-wave workgroup per CU: tickets vs a separate finalise launch measured equal, r04)
             in_kernel_bn = (pl.splitk == 1 || combine) && grid_wgs > RNR_FUSED_BN_MIN_WGS;
             if (in_kernel_bn) {
                 P.arrive = reinterpret_cast<unsigned*>(sb + L.arrive);
@@ -2347,7 +2348,7 @@ extern "C" int rnr_conv2d_ray(const rnr_conv_desc* d, const rnr_conv_src* src0, 
     if (int e = check_desc(d, "rnr_conv2d_ray")) return e;
     ConvPlan pl;
     rnr_conv_desc dd = *d;
-    dd.flags &= ~RNR_CONV_WINOGRAD;         // the ray-renderer epilogue lives in the direct 80-column kernel
+    dd.flags &= ~(RNR_CONV_WINOGRAD | RNR_CONV_WINOGRAD4);         // the ray-renderer epilogue lives in the direct 80-column kernel
     make_plan(&dd, num_views, in_h, in_w, &pl);
     RNR_REQUIRE(d->kind == RNR_CONV3x3_REFLECT && !(d->flags & RNR_CONV_F32_EMU_ANY) && pl.halo && pl.cfg == 1 && pl.tw == 32 &&
                     d->c_out % 3 == 0 && d->c_out_pad == 80,

@@ -116,7 +116,7 @@ class UNetPlan:
             desc.flags |= _lib.EMU_FLAGS[precision]
             if conv_algo != 'direct':
                 desc.flags |= _lib.CONV_WINOGRAD
-            if conv_algo == 'winograd4' and kind == CONV3x3_REFLECT:
+            if conv_algo == 'winograd4' and kind == CONV3x3_REFLECT and desc.c_out_pad % 64 == 0:
                 desc.flags |= _lib.CONV_WINOGRAD4
             if share_weights_with is not None:
                 packed = share_weights_with.steps[len(self.steps)]['packed']
@@ -274,7 +274,7 @@ class UNetPlan:
         out_desc = last['desc']
         if ray is not None and (out_desc.flags & _lib.CONV_WINOGRAD):
             out_desc = RnrConvDesc(out_desc.kind, out_desc.c_in0, out_desc.c_in0_pad, out_desc.c_in1, out_desc.c_in1_pad,
-                                   out_desc.c_out, out_desc.c_out_pad, out_desc.flags & ~_lib.CONV_WINOGRAD)
+                                   out_desc.c_out, out_desc.c_out_pad, out_desc.flags & ~(_lib.CONV_WINOGRAD | _lib.CONV_WINOGRAD4))
         self._out_desc = out_desc
         if consumer_alpha is not None:
             h, w = last['in_hw']
