@@ -691,3 +691,4 @@ def test_conv_winograd_f4x4_vs_torch(N, H, W, cins, c_out, algo):
     # the flag without its companion is refused
     with pytest.raises(RuntimeError, match='WINOGRAD4'):
         run_conv_fused(0, srcs, w, c_out, N, H, W, gamma, beta, flags=_lib.CONV_WINOGRAD4)
+
