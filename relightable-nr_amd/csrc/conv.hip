@@ -1753,6 +1753,9 @@ __global__ void __launch_bounds__(256) zero_f64_kernel(double* __restrict__ p, l
 #ifndef RNR_WINO2_MIN_WGS
 #define RNR_WINO2_MIN_WGS 200        // fewer workgroups (one per CU) than this: the direct kernels
 #endif
+#ifndef RNR_WINO4_SPLIT_MIN_CHUNKS
+#define RNR_WINO4_SPLIT_MIN_CHUNKS 4    // 16-channel chunks per split-K slice of conv_wino4_kernel, at least
+#endif
 #ifndef RNR_WINO4_MIN_WGS
 #define RNR_WINO4_MIN_WGS 256        // fewer 32 x 16 pixel x 64 column tiles than this (one 12-wave workgroup per CU): F(2x2, 3x3)
 #endif
@@ -1912,11 +1915,25 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     if ((d->flags & RNR_CONV_WINOGRAD) && (d->flags & RNR_CONV_WINOGRAD4) && d->kind == RNR_CONV3x3_REFLECT && H % W4_PH == 0 &&
         W % W4_PW == 0 && d->c_out_pad % W4_BN == 0 && view_elems < (1L << 30)) {
         const long wgs = (long)N * (H / W4_PH) * (W / W4_PW) * (d->c_out_pad / W4_BN);
-        if (wgs >= min_wgs4) {
+        // small grids are cut over K like the F(2x2, .) ones — slices of >= RNR_WINO4_SPLIT_MIN_CHUNKS chunks, at most 8, and the
+        // split grid must give every CU its workgroup again (this kernel runs one workgroup per CU)
+        int sk = wgs >= min_wgs4 ? 1 : 0;
+        if (!sk && wgs > 0) {
+            static const int enabled = [] { const char* e = getenv("RNR_WINO_SPLITK"); return e ? atoi(e) : 1; }();
+            int want = (int)((min_wgs4 + wgs - 1) / wgs);
+            const int max_sk = p->chunks_per_tap / RNR_WINO4_SPLIT_MIN_CHUNKS < 8 ? p->chunks_per_tap / RNR_WINO4_SPLIT_MIN_CHUNKS : 8;
+            if (want > max_sk) want = max_sk;
+            if (want >= 2) {
+                const int per = (p->chunks_per_tap + want - 1) / want;
+                want = (p->chunks_per_tap + per - 1) / per;         // no empty trailing slice
+            }
+            if (enabled && want >= 2 && wgs * want >= min_wgs4) sk = want;
+        }
+        if (sk) {
             p->wino = 4; p->halo = 1; p->cfg = 0; p->tw = W4_PW; p->bm = W4_PW * W4_PH; p->bn = W4_BN;
             p->mtiles = N * (H / W4_PH) * (W / W4_PW);
             p->ntiles = d->c_out_pad / W4_BN;
-            p->splitk = 1;
+            p->splitk = sk;
         }
     }
     // ... and the 80-column out layer on the 16 x 16 x 4 instruction: 16 x 4 pixel tiles x all 80 columns (conv_wino80_kernel)

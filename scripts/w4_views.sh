@@ -1,4 +1,2 @@
-for a in winograd winograd4; do echo "== $a views 1"; python scripts/layer_time.py --views 1 --$a --layers 1,2,4,6,8,19,21 2>/dev/null | grep "^L"; done
-for a in winograd winograd4; do echo "== $a views 2"; python scripts/layer_time.py --views 2 --$a --layers 1,4,6,8 2>/dev/null | grep "^L"; done
-for a in winograd winograd4; do echo "== $a views 4"; python scripts/layer_time.py --views 4 --$a --layers 4,6,8,10 2>/dev/null | grep "^L"; done
-echo "== min wgs 128, views 8 L10/L13; views 1 L6 L8"; RNR_WINO4_MIN_WGS=128 python scripts/layer_time.py --views 8 --winograd4 --layers 10,13 2>/dev/null | grep "^L"; RNR_WINO4_MIN_WGS=64 python scripts/layer_time.py --views 1 --winograd4 --layers 6,8,17 2>/dev/null | grep "^L"; RNR_WINO4_MIN_WGS=128 python scripts/layer_time.py --views 4 --winograd4 --layers 8 2>/dev/null | grep "^L"
+# usage (GPU box): bash scripts/w4_views.sh    F(2x2,3x3) vs F(4x4,3x3) (split over K where the grid is small) on the 3x3 layers by view count
+for V in 1 2 4 8; do for a in winograd winograd4; do echo "== $a views $V"; python scripts/layer_time.py --views $V --$a --layers 4,6,8,10 2>/dev/null | grep "^L"; done; done

@@ -122,3 +122,25 @@ def test_winograd_f4x4_plan_and_image_size():
     assert L.rnr_conv_algorithm(ctypes.byref(d), 8, 256, 240) == 1           # width not a multiple of 32
     assert L.rnr_conv_algorithm(ctypes.byref(desc(0, (128,), 128, _lib.CONV_WINOGRAD)), 8, 256, 256) == 1
     assert L.rnr_conv_workspace_bytes(ctypes.byref(d), 8, 256, 256) == 256   # never split over K
+
+
+def test_winograd_f4x4_split_grids():
+    """Small F(4x4, 3x3) grids are cut over K when the split grid gives every CU its workgroup again: slices of >= 4 chunks, no
+    empty slice, workspace = one partial-output slab per slice."""
+    L = _lib.load()
+    both = _lib.CONV_WINOGRAD | _lib.CONV_WINOGRAD4
+    for hw, c, views, want_sk in ((64, 512, 1, 4), (128, 256, 1, 2), (64, 512, 2, 2), (32, 512, 8, 2), (64, 512, 4, 1)):
+        d = desc(0, (c,), c, both)
+        assert L.rnr_conv_algorithm(ctypes.byref(d), views, hw, hw) == 4, (hw, c, views)
+        ws = L.rnr_conv_workspace_bytes(ctypes.byref(d), views, hw, hw)
+        sk = 1 if ws == 256 else ws // (views * hw * hw * c * 4)
+        assert sk == want_sk, (hw, c, views, sk)
+    # 32 x 32 at one view: 16 workgroups, 8 slices would give 128 < 256 -> F(2x2, 3x3) (64 of its tiles, split four ways)
+    assert L.rnr_conv_algorithm(ctypes.byref(desc(0, (512,), 512, both)), 1, 32, 32) == 1
+    for chunks in range(4, 40):
+        d = desc(0, (16 * chunks,), 64, both)
+        if L.rnr_conv_algorithm(ctypes.byref(d), 1, 128, 128) != 4:          # 32 workgroups
+            continue
+        sk = L.rnr_conv_workspace_bytes(ctypes.byref(d), 1, 128, 128) // (128 * 128 * 64 * 4)
+        per = -(-chunks // sk)
+        assert sk >= 2 and (sk - 1) * per < chunks and per >= 4 and 32 * sk >= 256, (chunks, sk)

@@ -649,6 +649,9 @@ WINO4_CASES = [
     (16, 64, 128, [32, 96], 64, 4),     # skip concat with unequal sources (2 + 6 chunks), non-square
     (2, 128, 128, [64, 64], 78, 3),     # 80 columns: no F(4x4, 3x3) image, the out layer's F(2x2, 3x3) kernel
     (4, 64, 72, [64], 64, 0),           # width not a multiple of 16: direct
+    (1, 64, 64, [512], 512, 4),         # 64 workgroups: F(4x4, 3x3) split four ways over K (partial outputs + splitk_reduce_kernel + finalise)
+    (1, 128, 128, [256], 256, 4),       # 128 workgroups: split two ways
+    (16, 32, 32, [272], 128, 4),        # 64 workgroups x 17 chunks: four slices of 5, 5, 5, 2 chunks (the last one short)
 ]
 
 
