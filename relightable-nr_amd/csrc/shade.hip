@@ -496,6 +496,32 @@ ray_render_kernel(const RayParams P) {
     float* s_raw = rr_smem;                                 // [PIX_PER_WG][c_out_pad]
     float* s_ni = rr_smem + PIX_PER_WG * P.c_out_pad;       // [PIX_PER_WG][ni_need]
     const int wg_valid = (int)min((long)PIX_PER_WG, P.npix - wg_pix0);
+    float al[RR_PIX];
+#pragma unroll
+    for (int k = 0; k < RR_PIX; k++) al[k] = (lp0 + k < wg_valid) ? wg_alpha[lp0 + k] : 0.0f;
+    {
+        // r04: a workgroup whose 32 pixels are all background writes its zeros and is done — the frame is exactly 0 there
+        // whatever the network produced (rays_uv = -1 masks every env-map tap, network.py:469-470, 497), so neither the 320 +
+        // 368 bytes per pixel of unet_raw / net_in nor the 26 rays are touched (bit-identical frames; about half of the bench
+        // scene's pixels)
+        int fg = 0;
+#pragma unroll
+        for (int k = 0; k < RR_PIX; k++) fg |= al[k] != 0.0f ? 1 : 0;
+        if (!__syncthreads_or(fg)) {
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < RR_PIX; k++) {
+                    if (lp0 + k >= wg_valid) continue;
+                    int rem = wg_rem0 + lp0 + k;
+                    long n = wg_n0;
+                    while (rem >= P.hw) { rem -= P.hw; n += 1; }
+#pragma unroll
+                    for (int c = 0; c < 3; c++) P.image[(n * 3 + c) * P.hw + rem] = 0.0f;
+                }
+            }
+            return;
+        }
+    }
     {
         const int q_raw = P.c_out_pad >> 2, q_ni = ni_need >> 2;
         const float4* g_raw = reinterpret_cast<const float4*>(wg_raw);
@@ -506,9 +532,6 @@ ray_render_kernel(const RayParams P) {
             reinterpret_cast<float4*>(s_ni)[i] = *reinterpret_cast<const float4*>(wg_net_in + (unsigned)(__mul24(p, P.c_pad) + 4 * q4));
         }
     }
-    float al[RR_PIX];
-#pragma unroll
-    for (int k = 0; k < RR_PIX; k++) al[k] = (lp0 + k < wg_valid) ? wg_alpha[lp0 + k] : 0.0f;
     __syncthreads();
     float dx[RR_PIX], dy[RR_PIX], dz[RR_PIX], y0[RR_PIX], y1[RR_PIX], y2[RR_PIX];
     bool live[RR_PIX];

@@ -210,3 +210,38 @@ def test_frame_prepare_equals_the_separate_launches(n_views):
     assert torch.equal(v2, v_ref)
     with pytest.raises(ValueError):
         ops.frame_prepare(mesh, K, pose, S, v_uvz=v[:, :-1].contiguous())
+
+
+def test_ray_render_background_workgroups_write_exact_zeros():
+    """r04: a ray_render workgroup whose 32 pixels are all background returns after writing zeros, without reading unet_raw /
+    net_in.  The frame must not depend on what those buffers hold on background pixels (NaN here), must be exactly 0 there, and
+    must equal the frame computed with finite garbage in their place — for fully covered, fully empty and mixed 32-pixel runs,
+    a ragged last workgroup included."""
+    from rnr_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, H, W, R = 2, 24, 44, 13                      # 2112 pixels = 66 workgroups of 32 pixels; view boundary inside a workgroup
+    c_pad, c_out_pad = 112, 80
+    dirs = torch.nn.functional.normalize(torch.randn(N, H, W, 2 * R, 3, generator=g), dim=-1)
+    net_in = torch.zeros(N, H, W, c_pad)
+    net_in[..., :6 * R] = dirs.reshape(N, H, W, 6 * R)
+    net_in[..., 6 * R + 6:6 * R + 12] = torch.rand(N, H, W, 6, generator=g)
+    raw = torch.randn(N, H, W, c_out_pad, generator=g)
+    bias = torch.randn(c_out_pad, generator=g) * 0.1
+    lp = torch.rand(20, 40, 3, generator=g)
+    alpha = torch.zeros(N * H * W)
+    alpha[100:700] = 1.0                            # whole workgroups inside, partial ones at both ends
+    alpha[1000:1003] = 1.0                          # three foreground pixels in one workgroup
+    alpha[2090:] = 1.0                              # up to the last pixel of the batch
+    alpha = alpha.reshape(N, H, W)
+    bg = alpha == 0
+    ref = ops.ray_render(raw.to(DEV), bias.to(DEV), net_in.to(DEV), alpha.to(DEV), lp.to(DEV), R, R).clone()
+    raw_p, ni_p = raw.clone(), net_in.clone()
+    raw_p[bg] = float('nan')                        # the out layer may have skipped the tile: garbage on every background pixel
+    # net_in is written by shade_inputs on every pixel (finite); only workgroups that are background throughout never read it
+    runs = bg.reshape(-1, 32).all(dim=1, keepdim=True).expand(-1, 32).reshape(N, H, W)
+    ni_p[runs] = float('nan')
+    assert int(runs.sum()) > 1000 and int((bg & ~runs).sum()) > 20
+    out = ops.ray_render(raw_p.to(DEV), bias.to(DEV), ni_p.to(DEV), alpha.to(DEV), lp.to(DEV), R, R)
+    assert torch.isfinite(out).all() and torch.equal(out, ref)
+    assert float(out.permute(0, 2, 3, 1)[bg.to(DEV)].abs().max()) == 0.0
+    assert float(out.permute(0, 2, 3, 1)[(~bg).to(DEV)].abs().max()) > 0.05
