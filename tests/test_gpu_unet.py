@@ -695,3 +695,26 @@ def test_conv_winograd_f4x4_vs_torch(N, H, W, cins, c_out, algo):
     with pytest.raises(RuntimeError, match='WINOGRAD4'):
         run_conv_fused(0, srcs, w, c_out, N, H, W, gamma, beta, flags=_lib.CONV_WINOGRAD4)
 
+
+
+@pytest.mark.parametrize('N,H,W,cins,c_out', [(1, 64, 64, [512], 512), (1, 128, 128, [256], 256), (16, 64, 64, [64], 128)])
+def test_conv_winograd_f4x4_legacy_entry_point_and_combine_ab(N, H, W, cins, c_out, monkeypatch):
+    """F(4x4, 3x3) through the legacy entry point rnr_conv2d (statistics into a caller buffer; a split grid writes slabs that
+    splitk_reduce_kernel adds) against float64, and — for the split grids — the product entry point's in-launch combine against
+    it: the same partial tiles are added in the same slice order, so out_raw is BIT-identical between the two paths."""
+    from rnr_amd import _lib
+    g = torch.Generator().manual_seed(4400 + H + c_out)
+    srcs = [(torch.randn(N, C, H, W, generator=g), torch.rand(N, C, generator=g) + 0.5, torch.randn(N, C, generator=g) * 0.3, 1)
+            for C in cins]
+    cin = sum(cins)
+    w = torch.randn(c_out, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    flags = _lib.CONV_WINOGRAD | _lib.CONV_WINOGRAD4
+    out, stats = run_conv(0, srcs, w, c_out, N, H, W, flags=flags)
+    ref = ref_conv(0, srcs, w).permute(0, 2, 3, 1)
+    assert torch.isfinite(out).all()
+    assert (out[..., :c_out].double() - ref).abs().max() < 1e-4 * ref.abs().max()
+    assert torch.allclose(stats[:, :c_out, 0], ref.sum(dim=(1, 2)), rtol=1e-4, atol=1e-3 * float(ref.abs().max()) * H * W ** 0.5)
+    assert torch.allclose(stats[:, :c_out, 1], (ref * ref).sum(dim=(1, 2)), rtol=1e-4)
+    gamma, beta = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
+    fused = run_conv_fused(0, srcs, w, c_out, N, H, W, gamma, beta, flags=flags)[0]
+    assert torch.equal(fused, out)
