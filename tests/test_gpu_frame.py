@@ -188,6 +188,43 @@ def test_frame512_nf64_vs_oracle(precision):
         assert (one - img8[i:i + 1]).abs().max() <= 1e-5, i
 
 
+def test_frame512_conv_algorithms_agree():
+    """The gate behind the default conv_algo, as a regression test on six views of the bench
+    workload: frames of the F(4x4, 3x3) product path ('winograd4'), of the F(2x2, .)-only path ('winograd') and of the direct
+    path agree to 1e-5 (measured over all 720 views: <= 1.8e-6, profiles/r04_winograd4_vs_direct_720views.json), at 8-view,
+    2-view and one-view calls (different plans: split grids at the small view counts), and every path is bit-stable run to run."""
+    import ctypes
+    from rnr_amd import scene
+    from rnr_amd.pipeline import RNRPipeline
+    S = 512
+    sc = _bench_scene()
+    mk = lambda algo: RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=64,
+                                  max_views=8, device=DEV, sh_coeff=sc['sh_coeff'], sh_lmax=10, skip_background_tiles=False,
+                                  conv_algo=algo)
+    ids = [37, 400, 5, 123, 250, 333, 600, 719]
+    dv = {k: T(v).to(DEV) for k, v in scene.spiral_views(S, ids).items()}
+    frames = {}
+    for algo in ('winograd4', 'winograd', 'direct'):
+        pipe = mk(algo)
+        assert pipe.unet.conv_algo == algo
+        r = lambda sl: pipe.render(dv['proj'][sl], dv['pose'][sl], dv['proj_inv'][sl], dv['R_inv'][sl]).clone()
+        f8 = r(slice(0, 8))
+        assert torch.equal(f8, r(slice(0, 8)))                          # bit-stable
+        f2 = r(slice(2, 4))
+        f1 = r(slice(5, 6))
+        assert (f2 - f8[2:4]).abs().max() <= 1e-5 and (f1 - f8[5:6]).abs().max() <= 1e-5
+        frames[algo] = (f8, f2, f1)
+        if algo == 'winograd4':
+            n4 = [sum(pipe.unet.L.rnr_conv_algorithm(ctypes.byref(st['desc']), V, *st['in_hw']) == 4 for st in pipe.unet.steps)
+                  for V in (8, 2, 1)]
+            assert n4[0] >= 9 and n4[1] >= 5 and n4[2] >= 5, n4
+        del pipe
+    for algo in ('winograd4', 'winograd'):
+        for a, b in zip(frames[algo], frames['direct']):
+            assert float((a - b).abs().max()) <= 1e-5, (algo, float((a - b).abs().max()))
+    assert float(frames['direct'][0].abs().max()) > 0.2
+
+
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 def test_frame512_nf64_vs_reference_run(golden, precision):
     """The frame at the benchmarked size against a REFERENCE-RUN fixture (tests/golden/make_golden.py::gen_frame512: the
