@@ -14,7 +14,7 @@
 //      covers <= 256 pixels walks them itself and folds (depth bits, face index) into a per-pixel 64-bit key
 //      with one atomicMin; a bigger trusted box is binned into the 16x16-pixel tiles it touches (exact,
 //      rounding-monotone tile test); untrusted boxes and huge faces go to a per-view wide list, which
-//      bin_wide_kernel tests against every tile.  (near < 0: bin_faces_kernel bins everything.)
+//      every tile of raster_tile_kernel tests against itself.  (near < 0: bin_faces_kernel bins everything.)
 //   3. raster_tile_kernel, one 256-thread workgroup per tile: evaluates the reference's per-candidate
 //      arithmetic for its binned candidates on LDS-broadcast face records — unordered lists, so the
 //      reference's "ascending faces, strict <" rule is applied in its order-free form (smallest zp, ties ->
@@ -163,9 +163,9 @@ __device__ __forceinline__ bool edge_rejects_tile(float xa, float ya, float xb, 
 // 1b. face-parallel binning: O(faces x tiles-per-face) instead of every tile scanning every face.
 //     Each kept face is appended (LDS-free, one global atomic per (face, tile)) to the candidate list of every tile
 //     whose exact tile test it survives.  Lists are unordered; the z-resolve is order-free.  Faces whose box is not
-//     trustworthy (BOX_EXACT) or spans many tiles go to a per-view "wide" list and are tested against all tiles by
-//     bin_wide_kernel with (face, tile) pairs spread over the whole grid.  A tile whose list overflows BIN_CAP
-//     falls back to scanning all boxes itself (raster_tile_kernel), so capacity never affects results.
+//     trustworthy (BOX_EXACT) or spans many tiles go to a per-view "wide" list, which every tile of raster_tile_kernel
+//     tests against itself (a launch of its own until r04: 10 - 26 us for a list that is empty on the bench scene).  A tile
+//     whose list overflows BIN_CAP falls back to scanning all boxes itself, so capacity never affects results.
 // ------------------------------------------------------------------------------------------------
 constexpr int BIN_CAP = 2048;
 constexpr int WIDE_TILES = 64;
@@ -210,29 +210,6 @@ bin_faces_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ bo
             if (face_may_touch_tile(f, tx, ty, is)) bin_append(tc, tl, ty * tiles_x + tx, fn);
 }
 
-__global__ void __launch_bounds__(256)
-bin_wide_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ boxes, int* __restrict__ tile_count,
-                int* __restrict__ tile_list, const int* __restrict__ wide_count, const int* __restrict__ wide_list,
-                int nf, int is) {
-    const int bn = blockIdx.y;
-    const int tiles_x = (is + TILE - 1) / TILE;
-    const int ntiles = tiles_x * tiles_x;
-    const long total = (long)wide_count[bn] * ntiles;
-    int* tc = tile_count + (size_t)bn * ntiles;
-    int* tl = tile_list + (size_t)bn * ntiles * BIN_CAP;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
-        const int fn = wide_list[(size_t)bn * nf + (int)(p / ntiles)];
-        const int t = (int)(p % ntiles);
-        const int tx = t % tiles_x, ty = t / tiles_x;
-        const FaceBox b = boxes[(size_t)bn * nf + fn];
-        if (b.xlo != BOX_EXACT) {   // a big but trustworthy box still prunes
-            const int tx0 = tx * TILE, ty0 = ty * TILE;
-            if (!(b.xlo <= tx0 + TILE - 1 && b.xhi >= tx0 && b.ylo <= ty0 + TILE - 1 && b.yhi >= ty0)) continue;
-        }
-        if (face_may_touch_tile(faces + ((size_t)bn * nf + fn) * 9, tx, ty, is)) bin_append(tc, tl, t, fn);
-    }
-}
-
 // The reference's per-(face, pixel) candidate arithmetic (rasterize_cuda_kernel.cu:115-139) on a 24-float face record
 //   r0 = (x0, y0, x1, y1)  r1 = (x2, y2, x1-x0, y1-y0)  r2 = (x2-x1, y2-y1, x0-x2, y0-y2)
 //   r3 = (inv0..3)  r4 = (inv4..7)  r5 = (inv8, z0, z1, z2)
@@ -272,7 +249,7 @@ __device__ __forceinline__ bool cand_depth(const float4 r3, const float4 r4, con
 //     it is filtered explicitly).  The path is only taken when near >= 0.
 //     Work: faces x box pixels (a pixel-sized face of the bench mesh: ~16-36 tests) instead of tiles x candidates x 256.
 //     Faces whose box cannot be trusted (BOX_EXACT) or covers more than SPLAT_MAX_PIX pixels go to the wide list and
-//     through bin_wide_kernel / the tile kernel as before; the tile kernel merges both results per pixel.
+//     to the tile kernel as before; the tile kernel merges both results per pixel.
 // ------------------------------------------------------------------------------------------------
 constexpr int SPLAT_MAX_PIX = 256;
 constexpr unsigned long long KEY_EMPTY = ~0ull;
@@ -290,7 +267,7 @@ splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ fa
     const float* f = faces + i * 9;
     if (b.xlo == BOX_EXACT || (xb - xa + 1) * (yb - ya + 1) > SPLAT_MAX_PIX) {
         // too big to walk pixel by pixel.  A trusted box over a few tiles is binned right here (bin_faces_kernel's loop);
-        // only untrusted boxes and huge faces take the wide list, whose (face, tile) pairs bin_wide_kernel tests against
+        // only untrusted boxes and huge faces take the wide list, whose faces the tile kernel tests against
         // EVERY tile — with every > 256-pixel face on it, a close-up of a coarse mesh cost wide x tiles pair tests
         const int tiles_x = (is + TILE - 1) / TILE;
         const int txa = xa / TILE, txb = xb / TILE, tya = ya / TILE, tyb = yb / TILE;
@@ -339,6 +316,8 @@ struct RasterParams {
     const int* tile_count;   // [B,ntiles]  candidates binned per tile (may exceed BIN_CAP: then the tile rescans)
     const int* tile_list;    // [B,ntiles,BIN_CAP]
     const unsigned long long* keys;   // [B,is,is] winners of the face-parallel path (KEY_EMPTY = none) or NULL
+    const int* wide_count;   // [B] faces on the wide list: untrusted or huge boxes, tested by every tile itself
+    const int* wide_list;    // [B,nf]
     int nf, is;
     float near_, far_;
     int flip;                // 1: write row (is-1-yi)
@@ -432,6 +411,38 @@ raster_tile_kernel(const RasterParams P) {
     const int binned = P.tile_count ? P.tile_count[(size_t)bn * ntiles_all + tile] : BIN_CAP + 1;
     const int nsteps = binned <= BIN_CAP ? 0 : (nf + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (binned <= BIN_CAP) process_queue(P.tile_list + ((size_t)bn * ntiles_all + tile) * BIN_CAP, binned);
+    // the wide list (untrusted boxes, faces over more than WIDE_TILES tiles): every tile tests it against itself — usually
+    // empty, and then this costs one scalar load where bin_wide_kernel cost a launch (r04).  A tile that rescans every face
+    // anyway (overflowed list) meets the wide faces there.
+    if (P.wide_count && binned <= BIN_CAP) {
+        const int wn = P.wide_count[bn];
+        const int* wl = P.wide_list + (size_t)bn * nf;
+        for (int w0 = 0; w0 < wn; w0 += RTHREADS) {
+            const int w = w0 + tid;
+            bool k = false;
+            int fn = 0;
+            if (w < wn) {
+                fn = wl[w];
+                const FaceBox b = boxes[fn];
+                if (b.xlo == BOX_EXACT || (b.xlo <= tx1 && b.xhi >= tx0 && b.ylo <= ty1 && b.yhi >= ty0))     // a big but trustworthy box still prunes
+                    k = face_may_touch_tile(faces + (size_t)fn * 9, tile % tiles_x, tile / tiles_x, is);
+            }
+            const unsigned long long bal = __ballot(k);
+            if (bal) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_qn, __popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (k) s_queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = fn;
+            }
+            __syncthreads();
+            const int qn = s_qn;
+            if (qn > QCAP - RTHREADS || w0 + RTHREADS >= wn) {      // block-uniform
+                process_queue(s_queue, qn);                        // ends with a barrier
+                if (tid == 0) s_qn = 0;
+                __syncthreads();
+            }
+        }
+    }
     FaceBox bx[SCAN_ITEMS];
     auto fetch_boxes = [&](int step) {
 #pragma unroll
@@ -696,9 +707,8 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
                            tile_list, wide_count, wide_list, batch, nf, is);
         if (int e = check_launch("bin_faces_kernel")) return e;
     }
-    hipLaunchKernelGGL(bin_wide_kernel, dim3(512, batch), dim3(256), 0, st, faces, boxes, tile_count, tile_list, wide_count,
-                       wide_list, nf, is);
-    if (int e = check_launch("bin_wide_kernel")) return e;
+    P->wide_count = wide_count;      // tested by the tile kernel (bin_wide_kernel's work, without its launch)
+    P->wide_list = wide_list;
     P->tile_count = tile_count;
     P->tile_list = tile_list;
     return 0;
