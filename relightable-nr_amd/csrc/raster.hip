@@ -10,6 +10,7 @@
 //      (same IEEE binary32 operation sequence as the reference, this file is built with
 //      -ffp-contract=off), and a conservative pixel bounding box.  Faces whose box cannot be trusted
 //      (degenerate / sliver / non-finite) are flagged and decided by the exact tile test below.
+//      (On the product path the setup shares the launch and the registers of step 2: setup_splat_faces_kernel.)
 //   2. splat_faces_kernel, one lane per (view, face) (near >= 0, the product path): a face whose trusted box
 //      covers <= 256 pixels walks them itself and folds (depth bits, face index) into a per-pixel 64-bit key
 //      with one atomicMin; a bigger trusted box is binned into the 16x16-pixel tiles it touches (exact,
@@ -63,15 +64,13 @@ __device__ __forceinline__ float pix_center(int i, int is) {
 // ------------------------------------------------------------------------------------------------
 // 1. per-face setup
 // ------------------------------------------------------------------------------------------------
+// Setup of face i: writes faces_out (GATHER) / faces_inv / boxes and leaves the same values in f / inv / box for a caller
+// that goes on with them (setup_splat_faces_kernel).  False = back face (inv undefined).
 template <bool GATHER>
-__global__ void __launch_bounds__(256)
-face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ v_uvz,
-                  const int32_t* __restrict__ fidx, float* __restrict__ faces_out,
-                  float* __restrict__ faces_inv, FaceBox* __restrict__ boxes, int batch, int nf, int nv,
-                  int is) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)batch * nf) return;
-    float f[9];
+__device__ __forceinline__ bool face_setup(long i, const float* __restrict__ faces_in, const float* __restrict__ v_uvz,
+                                           const int32_t* __restrict__ fidx, float* __restrict__ faces_out,
+                                           float* __restrict__ faces_inv, FaceBox* __restrict__ boxes, int nf, int nv, int is,
+                                           float (&f)[9], float (&inv)[9], FaceBox& box) {
     if (GATHER) {  // vertices_to_faces.py:4-25 fused in
         const int bn = (int)(i / nf), fn = (int)(i % nf);
 #pragma unroll
@@ -88,7 +87,6 @@ face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = faces_in[i * 9 + k];
     }
-    FaceBox box;
     if (backface(f)) {  // reference returns before writing: caller's zero fill stays (rasterize.py:163)
         box = empty_box();
         boxes[i] = box;
@@ -96,7 +94,7 @@ face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = 0.0f;
         }
-        return;
+        return false;
     }
     // ---- barycentric inverse, rasterize_cuda_kernel.cu:44-66 (operation order preserved) ----
     const float s = (float)is;
@@ -112,7 +110,7 @@ face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ 
     m[6] = py[0] - py[1]; m[7] = px[1] - px[0]; m[8] = px[0] * py[1] - px[1] * py[0];
     const float den = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
 #pragma unroll
-    for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = m[k] / den;
+    for (int k = 0; k < 9; k++) { inv[k] = m[k] / den; faces_inv[i * 9 + k] = inv[k]; }
 
     // ---- conservative pixel bounding box (double; DESIGN.md §Rasterizer gives the bound) ----
     const double x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
@@ -143,6 +141,20 @@ face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ 
         }
     }
     boxes[i] = box;
+    return true;
+}
+
+template <bool GATHER>
+__global__ void __launch_bounds__(256)
+face_setup_kernel(const float* __restrict__ faces_in, const float* __restrict__ v_uvz,
+                  const int32_t* __restrict__ fidx, float* __restrict__ faces_out,
+                  float* __restrict__ faces_inv, FaceBox* __restrict__ boxes, int batch, int nf, int nv,
+                  int is) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * nf) return;
+    float f[9], inv[9];
+    FaceBox box;
+    face_setup<GATHER>(i, faces_in, v_uvz, fidx, faces_out, faces_inv, boxes, nf, nv, is, f, inv, box);
 }
 
 // Exact conservative tile test.  The reference rejects pixel p for edge a->b iff
@@ -254,17 +266,14 @@ __device__ __forceinline__ bool cand_depth(const float4 r3, const float4 r4, con
 constexpr int SPLAT_MAX_PIX = 256;
 constexpr unsigned long long KEY_EMPTY = ~0ull;
 
-__global__ void __launch_bounds__(256)
-splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ faces_inv, const FaceBox* __restrict__ boxes,
-                   unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
-                   int* __restrict__ wide_count, int* __restrict__ wide_list, int batch, int nf, int is, float near_, float far_) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)batch * nf) return;
-    const int bn = (int)(i / nf), fn = (int)(i % nf);
-    const FaceBox b = boxes[i];
+// f / fi: the face's 9 + 9 floats (global memory or the registers of the setup that has just produced them)
+template <typename FP>
+__device__ __forceinline__ void splat_face(long i, int bn, int fn, const FaceBox b, FP f, FP fi,
+                                           unsigned long long* __restrict__ keys, int* __restrict__ tile_count,
+                                           int* __restrict__ tile_list, int* __restrict__ wide_count, int* __restrict__ wide_list,
+                                           int nf, int is, float near_, float far_) {
     if (b.xlo != BOX_EXACT && b.xlo > b.xhi) return;                    // empty_box(): culled / off-screen
     const int xa = max((int)b.xlo, 0), xb = b.xhi, ya = max((int)b.ylo, 0), yb = b.yhi;
-    const float* f = faces + i * 9;
     if (b.xlo == BOX_EXACT || (xb - xa + 1) * (yb - ya + 1) > SPLAT_MAX_PIX) {
         // too big to walk pixel by pixel.  A trusted box over a few tiles is binned right here (bin_faces_kernel's loop);
         // only untrusted boxes and huge faces take the wide list, whose faces the tile kernel tests against
@@ -283,7 +292,6 @@ splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ fa
         wide_list[(size_t)bn * nf + pos] = fn;
         return;
     }
-    const float* fi = faces_inv + i * 9;
     const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
     const float4 r0 = make_float4(x0, y0, x1, y1);
     const float4 r1 = make_float4(x2, y2, x1 - x0, y1 - y0);
@@ -304,6 +312,36 @@ splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ fa
             atomicMin(kv + (size_t)yi * is + xi, key);
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ faces_inv, const FaceBox* __restrict__ boxes,
+                   unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
+                   int* __restrict__ wide_count, int* __restrict__ wide_list, int batch, int nf, int is, float near_, float far_) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * nf) return;
+    splat_face<const float*>(i, (int)(i / nf), (int)(i % nf), boxes[i], faces + i * 9, faces_inv + i * 9, keys, tile_count,
+                             tile_list, wide_count, wide_list, nf, is, near_, far_);
+}
+
+// face_setup_kernel + splat_faces_kernel in one launch (r04): both are one lane per (view, face) and the splat needs nothing
+// but its own face's record, which it takes from the registers of the setup — the same values the setup writes for the tile
+// kernel, hence the same bits as the two launches (tests/test_gpu_raster.py).
+struct FaceSetupArgs { const float* faces_in; const float* v_uvz; const int32_t* fidx; float* faces_out; int nv; int gather; };
+template <bool GATHER>
+__global__ void __launch_bounds__(256)
+setup_splat_faces_kernel(const float* __restrict__ faces_in, const float* __restrict__ v_uvz, const int32_t* __restrict__ fidx,
+                         float* __restrict__ faces_out, float* __restrict__ faces_inv, FaceBox* __restrict__ boxes,
+                         unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
+                         int* __restrict__ wide_count, int* __restrict__ wide_list, int batch, int nf, int nv, int is,
+                         float near_, float far_) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * nf) return;
+    float f[9], inv[9];
+    FaceBox box;
+    if (!face_setup<GATHER>(i, faces_in, v_uvz, fidx, faces_out, faces_inv, boxes, nf, nv, is, f, inv, box)) return;
+    splat_face<const float (&)[9]>(i, (int)(i / nf), (int)(i % nf), box, f, inv, keys, tile_count, tile_list, wide_count,
+                                   wide_list, nf, is, near_, far_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -677,8 +715,9 @@ raster_clear_kernel(uint4* __restrict__ counters, long counter_vec, uint4* __res
 }
 
 // fills P.tile_count / P.tile_list / P.keys.
+// setup != NULL: the per-face setup has not run yet; on the splat path it shares the splat's launch, otherwise it is launched first
 static int run_binning(char* ws, const float* faces, const float* faces_inv, const FaceBox* boxes, int batch, int nf, int is,
-                       RasterParams* P, hipStream_t st, bool precleared = false) {
+                       RasterParams* P, hipStream_t st, bool precleared = false, const FaceSetupArgs* setup = nullptr) {
     const int ntiles = num_tiles(is);
     int* tile_count = reinterpret_cast<int*>(ws);
     int* wide_count = tile_count + (size_t)batch * ntiles;
@@ -697,8 +736,27 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
                            reinterpret_cast<uint4*>(tile_count), cvec, reinterpret_cast<uint4*>(keys), kvec);
         if (int e = check_launch("raster_clear_kernel")) return e;
     }
-    if (splat) {
-        hipLaunchKernelGGL(splat_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, faces_inv, boxes,
+    const dim3 fgrid((unsigned)((total + 255) / 256));
+    float* faces_inv_w = const_cast<float*>(faces_inv);
+    FaceBox* boxes_w = const_cast<FaceBox*>(boxes);
+    if (setup && !splat) {
+        if (setup->gather) hipLaunchKernelGGL(face_setup_kernel<true>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz, setup->fidx,
+                                              setup->faces_out, faces_inv_w, boxes_w, batch, nf, setup->nv, is);
+        else hipLaunchKernelGGL(face_setup_kernel<false>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz, setup->fidx,
+                                setup->faces_out, faces_inv_w, boxes_w, batch, nf, setup->nv, is);
+        if (int e = check_launch("face_setup_kernel")) return e;
+    }
+    if (splat && setup) {
+        if (setup->gather) hipLaunchKernelGGL(setup_splat_faces_kernel<true>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz,
+                                              setup->fidx, setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list,
+                                              wide_count, wide_list, batch, nf, setup->nv, is, P->near_, P->far_);
+        else hipLaunchKernelGGL(setup_splat_faces_kernel<false>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz,
+                                setup->fidx, setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list,
+                                wide_count, wide_list, batch, nf, setup->nv, is, P->near_, P->far_);
+        if (int e = check_launch("setup_splat_faces_kernel")) return e;
+        P->keys = keys;
+    } else if (splat) {
+        hipLaunchKernelGGL(splat_faces_kernel, fgrid, dim3(256), 0, st, faces, faces_inv, boxes,
                            keys, tile_count, tile_list, wide_count, wide_list, batch, nf, is, P->near_, P->far_);
         if (int e = check_launch("splat_faces_kernel")) return e;
         P->keys = keys;
@@ -735,17 +793,14 @@ extern "C" int rnr_forward_face_index_map(const float* faces, int32_t* face_inde
     RNR_REQUIRE(!return_depth || face_inv_map, "rnr_forward_face_index_map: return_depth needs face_inv_map");
     hipStream_t st = as_stream(stream);
     FaceBox* boxes = reinterpret_cast<FaceBox*>(workspace);
-    const long total = (long)batch_size * num_faces;
-    hipLaunchKernelGGL(face_setup_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces,
-                       nullptr, nullptr, nullptr, faces_inv, boxes, batch_size, num_faces, 0, image_size);
-    if (int e = check_launch("face_setup_kernel")) return e;
+    const FaceSetupArgs setup = {faces, nullptr, nullptr, nullptr, 0, 0};
     RasterParams P = {};
     P.faces = faces; P.faces_inv = faces_inv; P.boxes = boxes; P.nf = num_faces; P.is = image_size;
     P.near_ = near_; P.far_ = far_; P.flip = 0;
     P.face_index_map = face_index_map; P.weight_map = weight_map; P.depth_map = depth_map;
     P.face_inv_map = return_depth ? face_inv_map : nullptr;
     if (int e = run_binning(reinterpret_cast<char*>(workspace) + box_bytes(batch_size, num_faces), faces, faces_inv, boxes,
-                            batch_size, num_faces, image_size, &P, st)) return e;
+                            batch_size, num_faces, image_size, &P, st, false, &setup)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<0>, dim3(tiles * tiles, batch_size), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<0>");
@@ -818,17 +873,13 @@ static int rasterize_gbuffer_impl(const rnr_mesh* mesh, const float* v_uvz, cons
     FaceBox* boxes = reinterpret_cast<FaceBox*>(ws);
     float* faces = reinterpret_cast<float*>(ws + box_bytes(num_views, nf));
     float* faces_inv = reinterpret_cast<float*>(ws + box_bytes(num_views, nf) + face_bytes(num_views, nf));
-    const long total = (long)num_views * nf;
-    hipLaunchKernelGGL(face_setup_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nullptr,
-                       v_uvz, mesh->f_v_idx, faces, faces_inv, boxes, num_views, nf, mesh->num_vertices,
-                       image_size);
-    if (int e = check_launch("face_setup_kernel<gather>")) return e;
+    const FaceSetupArgs setup = {nullptr, v_uvz, mesh->f_v_idx, faces, mesh->num_vertices, 1};
     RasterParams P = {};
     P.faces = faces; P.faces_inv = faces_inv; P.boxes = boxes; P.nf = nf; P.is = image_size;
     P.near_ = near_; P.far_ = far_; P.flip = 1;
     P.mesh = *mesh; P.gb = *out; P.pose = pose;
     if (int e = run_binning(ws + box_bytes(num_views, nf) + 2 * face_bytes(num_views, nf), faces, faces_inv, boxes, num_views,
-                            nf, image_size, &P, st, precleared)) return e;
+                            nf, image_size, &P, st, precleared, &setup)) return e;
     const int tiles = (image_size + TILE - 1) / TILE;
     hipLaunchKernelGGL(raster_tile_kernel<1>, dim3(tiles * tiles, num_views), dim3(RTHREADS), 0, st, P);
     return check_launch("raster_tile_kernel<1>");
