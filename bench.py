@@ -40,7 +40,8 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--views-per-step', type=int, default=8, help='camera poses per GPU per step')
+    ap.add_argument('--views-per-step', type=int, default=16,
+                    help='camera poses per GPU per step (r04: 16; 8 until then — 2, 4, 8, 16, 32 views per step measure 483, 527, 547, 557, 561 frames/s)')
     ap.add_argument('--img-size', type=int, default=512)
     ap.add_argument('--nf0', type=int, default=64)
     ap.add_argument('--tex-ch', type=int, default=24)
@@ -409,9 +410,9 @@ def single_view_block(sc, args, dev):
         'views_per_call': 1, 'views': n1,
         'workload': 'test_rnr.py:265-393: spiral_step720 views in order, one view per call, %dx%d, full HIP RenderingNet' % (args.img_size, args.img_size),
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view + one split-K reduce and one finalise launch for the '
-                                                  '64^2 -> 32^2 stride-2 layer; everywhere else the BatchNorm finalise and the split-K combine '
-                                                  'happen inside the conv launch; HIP events bracket the U-Net stage of every call)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view; the split-K Winograd layers are '
+                                                  'followed by a reduce launch and the one-workgroup-per-CU grids by a BatchNorm finalise launch of their own: '
+                                                  '12 + 13 launches at 512^2, profiles/r04_frame_timeline_f32_views1.txt; HIP events bracket the U-Net stage of every call)',
                      **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
                      'alg_flops_per_view': flops_view, 'traffic': traffic,
                      'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
@@ -682,6 +683,22 @@ def main(argv=None):
             torch.cuda.synchronize()
             return time.perf_counter() - t1
 
+        if extras and not fast and world == 1 and V > 8:
+            # the batch size of the rounds before r04, same pipeline object (a call may carry fewer views than max_views)
+            def st8(s):
+                lo = (s % (args.steps + args.warmup)) * 8
+                sl = slice(lo, lo + 8)
+                return pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
+            for s in range(2):
+                st8(s)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            for s in range(args.steps):
+                st8(s)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter() - t8
+            res['with_8_views_per_step'] = {'frames_per_s': args.steps * 8 / t8, 'ms_per_step': t8 / args.steps * 1e3,
+                                            'note': 'the headline batch size of r02 / r03; not the headline value'}
         if extras and not fast and world == 1 and not args.tile_skip and out_tiles_per_step:
             # product-tuned configuration of RNRPipeline, reported beside the headline (frames are bit-identical /
             # equal to 1e-6): out-layer pixel tiles without a foreground pixel are not computed, and the batch is split
