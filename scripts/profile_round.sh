@@ -19,7 +19,7 @@ for cfg in f32:16:winograd4 f32:1:winograd4 f32:16:winograd f32:16:direct f16x3:
       --views-per-step $v --no-cpu-baseline --main-loop-only --precision $prec --conv-algo $algo > $OUT/kt_${name}_$v.log 2>&1
   find $OUT/kt_${name}_$v -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats_${name}_steps${steps}_views$v.csv
   [ $v = 1 ] && find $OUT/kt_${name}_$v -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_trace_views1.csv
-  tail -1 $OUT/kt_${name}_$v.log > $OUT/${TAG}_bench_line_under_profiler_${name}_views$v.json
+  grep "^{\"metric\"" $OUT/kt_${name}_$v.log | tail -1 > $OUT/${TAG}_bench_line_under_profiler_${name}_views$v.json
   rm -rf $OUT/kt_${name}_$v
 done
 cd $ROOT
@@ -42,5 +42,5 @@ RNR_WINO_MIN_WGS=1 RNR_WINO2_MIN_WGS=1 timeout 600 python scripts/wino_check.py 
 RNR_WINO4_MIN_WGS=1 RNR_WINO_MIN_WGS=1 RNR_WINO2_MIN_WGS=1 timeout 600 python scripts/wino_check.py --views 2 --f4x4 > $OUT/${TAG}_winograd_f4x4_accuracy.txt 2>&1
 timeout 900 python scripts/wino_frames_720.py winograd4 > $OUT/${TAG}_winograd4_vs_direct_720views.json 2> $OUT/wf4.err
 timeout 900 python bench.py --pmc-file $OUT/${TAG}_pmc_per_kernel_f32_steps2_views16.json > $OUT/bench.log 2>&1
-tail -1 $OUT/bench.log > $OUT/${TAG}_bench_final.json
+grep "^{\"metric\"" $OUT/bench.log | tail -1 > $OUT/${TAG}_bench_final.json
 ls -la $OUT
