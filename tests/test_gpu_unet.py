@@ -718,3 +718,58 @@ def test_conv_winograd_f4x4_legacy_entry_point_and_combine_ab(N, H, W, cins, c_o
     gamma, beta = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g)
     fused = run_conv_fused(0, srcs, w, c_out, N, H, W, gamma, beta, flags=flags)[0]
     assert torch.equal(fused, out)
+
+
+FULL_SIZE_LAYERS = [
+    # kind, H, [C per source], c_out, Winograd algorithm expected at N = 4        the U-Net layer of SURVEY App. A it stands for
+    (0, 512, [64], 64, 4),              # L2 / L21: conv_wino4_kernel, 4 chunks
+    (0, 512, [64, 64], 78, 3),          # L22: the 80-column out layer (conv_wino80_kernel)
+    (1, 512, [64], 128, 2),             # L3: 4x4 stride 2 (conv_wino2_kernel<1>)
+    (2, 256, [128, 128], 64, 2),        # L20: transposed 4x4 stride 2 over the skip concat (conv_wino2_kernel<2>)
+]
+
+
+@pytest.mark.parametrize('kind,H,cins,c_out,algo', FULL_SIZE_LAYERS)
+def test_winograd_layers_at_full_size_properties(kind, H, cins, c_out, algo):
+    """The benchmark's own layer sizes (512^2 / 256^2 maps, too big for a CPU convolution in a test) through size-independent
+    properties: (1) the product kernel agrees with the direct kernel on the same input, (2) linearity: conv(a x + b y) =
+    a conv(x) + b conv(y), (3) the statistics the launch returns are the sums over the output it wrote (a checksum of
+    checksums, float64), (4) 3x3 only: the same image shifted by one pixel (tile phase of the F(4x4) / F(2x2) tiling changes
+    for every output) gives the shifted result away from the borders.  Tolerance 1e-4 of the output peak, as for the small
+    shapes that are checked against torch."""
+    from rnr_amd import _lib
+    N = 4
+    g = torch.Generator().manual_seed(7000 + kind * 13 + H + c_out)
+    cin = sum(cins)
+    k = 3 if kind == 0 else 4
+    w = (torch.randn(c_out, cin, k, k, generator=g) if kind != 2 else torch.randn(cin, c_out, k, k, generator=g)) / (cin * k * k / (4 if kind == 2 else 1)) ** 0.5
+    xs = [torch.randn(N, C, H, H, generator=g) for C in cins]
+    ys = [torch.randn(N, C, H, H, generator=g) for C in cins]
+    flags = _lib.CONV_WINOGRAD | _lib.CONV_WINOGRAD4
+    pad16 = lambda c: (c + 15) // 16 * 16
+    desc = _lib.RnrConvDesc(kind, cins[0], pad16(cins[0]), cins[1] if len(cins) > 1 else 0, pad16(cins[1]) if len(cins) > 1 else 0,
+                            c_out, pad16(c_out), flags)
+    assert _lib.load().rnr_conv_algorithm(ctypes.byref(desc), N, H, H) == algo
+    plain = lambda ts: [(t, None, None, 0) for t in ts]
+    ox, sx = run_conv(kind, plain(xs), w, c_out, N, H, H, flags=flags)
+    od, _ = run_conv(kind, plain(xs), w, c_out, N, H, H, flags=0)
+    peak = float(od[..., :c_out].abs().max())
+    assert torch.isfinite(ox).all() and float((ox - od)[..., :c_out].abs().max()) < 1e-4 * peak
+    # (3) statistics = sums over the written output
+    o64 = ox[..., :c_out].double()
+    s1, s2 = o64.sum(dim=(1, 2)), (o64 * o64).sum(dim=(1, 2))
+    # (per-lane partial sums of 16 - 48 outputs are float32, everything above them float64)
+    assert torch.allclose(sx[:, :c_out, 0], s1, rtol=1e-6, atol=1e-6 * float(s2.max()) ** 0.5)
+    assert torch.allclose(sx[:, :c_out, 1], s2, rtol=1e-6)
+    # (2) linearity
+    a, b = 0.75, -1.5
+    oy, _ = run_conv(kind, plain(ys), w, c_out, N, H, H, flags=flags)
+    oz, _ = run_conv(kind, plain([a * x + b * y for x, y in zip(xs, ys)]), w, c_out, N, H, H, flags=flags)
+    lin = a * ox + b * oy
+    assert float((oz - lin)[..., :c_out].abs().max()) < 1e-4 * float(lin[..., :c_out].abs().max())
+    # (4) tile phase
+    if kind == 0:
+        sh = [torch.roll(x, shifts=(1, 1), dims=(2, 3)) for x in xs]
+        osh, _ = run_conv(kind, plain(sh), w, c_out, N, H, H, flags=flags)
+        d = (osh[:, 3:-3, 3:-3, :c_out] - ox[:, 2:-4, 2:-4, :c_out]).abs().max()
+        assert float(d) < 1e-4 * peak, float(d)
