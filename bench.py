@@ -55,8 +55,9 @@ def parse(argv=None):
                     help="conv arithmetic of the timed loop: exact fp32 MFMA (default, the headline) or fp32 emulated on the bf16 "
                          "matrix cores (RNR_CONV_F32_EMU_BF16X6)")
     ap.add_argument('--conv-algo', default=None, choices=['winograd', 'winograd4', 'direct'],
-                    help='U-Net convolution algorithm (rnr_amd.unet.UNetPlan conv_algo; default: the library default, winograd — '
-                         'fp32 Winograd F(2x2,3x3) / F(2x2,2x2) on the f32 MFMA; direct = every layer as a direct implicit GEMM)')
+                    help='U-Net convolution algorithm (rnr_amd.unet.UNetPlan conv_algo; default: the library default, winograd4 — fp32 Winograd '
+                         'F(4x4,3x3) on the 3x3 layers whose grid fills the chip, F(2x2,3x3) / F(2x2,2x2) elsewhere, all on the f32 MFMA; '
+                         'winograd = F(2x2, .) only (the r03 path); direct = every layer as a direct implicit GEMM)')
     ap.add_argument('--pmc-file', default=None,
                     help='merged.json written by scripts/pmc.sh (rocprofv3 --pmc passes over THIS command line at the same '
                          '--views-per-step / --precision): source of roofline.traffic.  Without it the newest committed '
@@ -69,6 +70,7 @@ def parse(argv=None):
                     help='skip the per-stage and single-view extras after the timed loop (rocprofv3 runs: every kernel launch in the profile then belongs to a timed or warm-up step)')
     ap.add_argument('--single-views', type=int, default=720,
                     help='views of the single_view_mode block (default: the whole spiral_step720 trajectory, as test_rnr.py renders it)')
+    ap.add_argument('--no-dropin-loop', action='store_true', help='skip the dropin_view_loop block (INTEGRATION.md Level 1 timing)')
     ap.add_argument('--stub-pipeline', action='store_true',
                     help='TEST HOOK (tests/test_bench_flow_cpu.py): run the control flow of this file — pose slicing, overlapped '
                          'frame gather, barrier + MAX-reduced timing, rank-0-only JSON, --check-gather — on CPU tensors with the '
@@ -427,6 +429,92 @@ def single_view_block(sc, args, dev):
     }
 
 
+def dropin_view_loop_block(sc, args, dev):
+    """INTEGRATION.md Level 1 on the record: test_rnr.py:265-377's own call sequence through the DROP-IN modules
+    (rnr_amd.view_loop.DropinViewLoop: network.Rasterizer -> render.get_TBN_map -> camera.get_view_dir_map -> torch.matmul ->
+    sph_harm.evaluate_sh_basis -> TextureMapper -> 2 x RaySampler -> torch.cat -> RenderingNet -> post-scale -> RayRenderer), one
+    view per call over the spiral_step720 views, nothing fused, the reference's intermediate tensors materialised in HBM.
+      frames_per_s               wall clock over the views, test_rnr.py:322-328 verbatim (view directions to host numpy, basis back
+                                 as float64 numpy, cast, upload: the host round trips the reference's numpy contract mandates);
+      sh_basis_on_device         the same loop with the one-line variant evaluate_sh_basis(..., as_tensor=True);
+      stage_ms                   HIP events at the call boundaries (mean over 48 views of each variant)."""
+    import tempfile
+    from rnr_amd import scene
+    from rnr_amd.view_loop import DropinViewLoop, stage_table
+    n1 = max(8, int(args.single_views))
+    ids = np.arange(n1) % 720
+    pv = {k: torch.from_numpy(v).to(dev) for k, v in scene.spiral_views(args.img_size, ids).items()}
+
+    def pose(i):
+        return pv['proj'][i:i + 1], pv['pose'][i:i + 1], pv['proj_inv'][i:i + 1], pv['R_inv'][i:i + 1]
+    with tempfile.TemporaryDirectory() as td:
+        obj = os.path.join(td, 'mesh.obj')
+        scene.write_obj(obj, sc['mesh'])
+        t0 = time.perf_counter()
+        loop = DropinViewLoop(obj, args.img_size, sc['textures'], sc['unet_sd'], sc['sh_coeff'], nf0=args.nf0, device=dev)
+        t_build = time.perf_counter() - t0
+    out = {}
+    last = {}
+    for tag, on_dev in (('numpy_contract', False), ('sh_basis_on_device', True)):
+        loop.sh_on_device = on_dev
+        for i in range(5):
+            loop.view(*pose(i))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = None
+        for i in range(n1):
+            img = loop.view(*pose(i))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n1
+        last[tag] = img.clone()
+        evs = []
+        for i in range(48):
+            e = []
+            loop.view(*pose(i), events=e)
+            evs.append(e)
+        torch.cuda.synchronize()
+        tab = stage_table(evs)
+        out[tag] = {'frames_per_s': 1.0 / dt, 'ms_per_frame': dt * 1e3, 'stage_ms': tab, 'stage_ms_sum': float(sum(tab.values()))}
+    # the same pose through the fused Level-2 pipeline
+    pipe = make_pipeline(sc, args, dev, 1)
+    ref = pipe.render(*pose(n1 - 1))
+    diff = {k: float((v - ref).abs().max()) for k, v in last.items()}
+    del pipe, loop
+    worst = max(out['numpy_contract']['stage_ms'].items(), key=lambda kv: kv[1])
+    return {
+        'workload': 'test_rnr.py:265-377 call by call through the drop-in modules (INTEGRATION.md Level 1), %d spiral_step720 views '
+                    'in order, one view per call, %dx%d, 65536 faces, nf0=%d' % (n1, args.img_size, args.img_size, args.nf0),
+        'frames_per_s': out['numpy_contract']['frames_per_s'], 'ms_per_frame': out['numpy_contract']['ms_per_frame'],
+        'stage_ms': out['numpy_contract']['stage_ms'], 'stage_ms_sum': out['numpy_contract']['stage_ms_sum'],
+        'slowest_stage': {'name': worst[0], 'ms': worst[1]},
+        'sh_basis_on_device': out['sh_basis_on_device'],
+        'max_abs_diff_vs_fused_pipeline_last_frame': diff,
+        'module_construction_s': t_build,
+        'note': 'frames_per_s keeps the reference\'s numpy contract for the SH basis (sph_harm.py:41-71: host numpy in, float64 numpy '
+                'out, then .astype(float32) and torch.from_numpy(...).to(device) in test_rnr.py:324-328): two host round trips and a '
+                'stream drain per view that no drop-in can remove; sh_basis_on_device is the same loop with '
+                'evaluate_sh_basis(..., as_tensor=True).  stage_ms are HIP-event intervals between the reference\'s own call boundaries '
+                '(host-side waits of a stage appear in it as idle GPU time).  Not the headline value.',
+    }
+
+
+def workload_name(args, world, V, sc):
+    """config.workload: which BASELINE.json config the line measures.  N = 1: configs[2] (spiral_step720 at 512^2, full HIP
+    RenderingNet on one MI355X) in V-view batches.  N > 1: configs[3] (spiral_step720 views sharded across the GPUs of one node,
+    frames all-gathered over RCCL / xGMI) with the global batch stated: configs[3] quotes batch = 64 on 8 GPUs (8 per GPU); the
+    headline keeps the N = 1 line's per-GPU batch so that per-GPU work is the same at every N (weak scaling), and the exact
+    configs[3] batch (8 views per GPU) is timed in the same run as `with_8_views_per_gpu`."""
+    net = ('%dx%d, full HIP RenderingNet (f32 MFMA convs + SH relight), UV-sphere 65536 faces, neural texture 512^2 x %d ch x 4 '
+           'levels, U-Net %d->%d nf0=%d' % (args.img_size, args.img_size, args.tex_ch, sc['c_in'], 3 * sc['n_rays'], args.nf0))
+    if world == 1:
+        return ('BASELINE configs[2] in %d-view batches (the reference renders 1 view per call; that mode is reported as '
+                'single_view_mode with its own roofline): test_rnr.py spiral_step720 views, %s' % (V, net))
+    return ('BASELINE configs[3]: spiral_step720 views sharded across %d x MI355X, one process per GPU, frames all-gathered over RCCL / '
+            'xGMI every step; GLOBAL batch = %d views per step = %d per GPU x %d GPUs (configs[3] quotes batch = 64 = 8 per GPU on 8 '
+            'GPUs; this line keeps the N = 1 headline\'s %d views per GPU so that per-GPU work is fixed across N — weak scaling — and '
+            'the 8-per-GPU batch of configs[3] is timed in the same run as with_8_views_per_gpu); %s' % (world, world * V, V, world, V, net))
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` WITHOUT a launcher: become the launcher.  Starts N copies of this command line, one per GPU,
     with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (127.0.0.1, a port the kernel hands out), passes their
@@ -566,6 +654,35 @@ def main(argv=None):
         gather_check = {'ok': int(bad.sum().item()) == 0, 'ranks_with_mismatch': int(bad[0].item()),
                         'gathered_shape': list(gather.latest.shape), 'backend': dist.get_backend()}
     last_frame = img[V - 1:V].clone()       # the frame buffers are reused by the extra renders below
+    # N > 1: BASELINE configs[3]'s own batch — 8 views per GPU (64 at 8 GPUs) — through the same pipeline, gather and timing
+    # protocol, every rank taking part; reported beside the headline as with_8_views_per_gpu
+    dt8 = None
+    V8 = 8 if not stub else max(1, V // 2)
+    if use_dist and world > 1 and V > V8 and os.environ.get('RNR_BENCH_FAST') != '1':
+        from rnr_amd.dist import OverlappedFrameGather
+        gather8 = OverlappedFrameGather(world, (V8, 3, args.img_size, args.img_size), torch.float32, dev)
+
+        def step8(s_):
+            lo = ((s_ * world + rank) * V8) % (n_total - V8 + 1)
+            sl = slice(lo, lo + V8)
+            gather8.submit(pipe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl]))
+        for s_ in range(max(1, args.warmup)):
+            step8(s_)
+        gather8.drain()
+        dist.barrier()
+        sync()
+        t8 = time.perf_counter()
+        for s_ in range(args.steps):
+            step8(s_)
+        gather8.drain()
+        sync()
+        dist.barrier()
+        sync()
+        dt8 = time.perf_counter() - t8
+        t8max = torch.tensor([dt8], device=dev, dtype=torch.float64)
+        dist.all_reduce(t8max, op=dist.ReduceOp.MAX)
+        dt8 = float(t8max.item())
+        del gather8
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -610,12 +727,9 @@ def main(argv=None):
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'n_ranks_seen': n_ranks_seen, 'rccl_version': rccl,
-            'config': {'workload': 'BASELINE configs[2] in %d-view batches (the reference renders 1 view per call; that mode is '
-                                   'reported as single_view_mode with its own roofline): test_rnr.py spiral_step720 views, %dx%d, full HIP RenderingNet '
-                                   '(f32 MFMA convs + SH relight), UV-sphere 65536 faces, neural texture 512^2 x %d ch x 4 '
-                                   'levels, U-Net %d->%d nf0=%d' % (V, args.img_size, args.img_size, args.tex_ch, sc['c_in'],
-                                                                   3 * sc['n_rays'], args.nf0),
-                       'views_per_step_per_gpu': V, 'parallelism': 'views sharded x%d, all_gather of frames' % world,
+            'config': {'workload': workload_name(args, world, V, sc),
+                       'views_per_step_per_gpu': V, 'global_views_per_step': world * V,
+                       'parallelism': 'views sharded x%d, all_gather of frames' % world,
                        'conv_algo': None if stub else pipe.unet.conv_algo},
             'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_wino80_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
                          **algo8, 'traffic': traffic,
@@ -633,6 +747,12 @@ def main(argv=None):
             res['cpu_baseline'] = None
         if gather_check is not None:
             res['gather_check'] = gather_check
+        if dt8 is not None:
+            res['with_8_views_per_gpu'] = {
+                'frames_per_s': args.steps * world * V8 / dt8, 'ms_per_step': dt8 / args.steps * 1e3,
+                'views_per_step_per_gpu': V8, 'global_views_per_step': world * V8,
+                'note': 'BASELINE configs[3] batch (8 views per GPU; 64 at 8 GPUs) with the same barrier + MAX-over-ranks protocol; '
+                        'not the headline value'}
     if rank == 0 and not stub:
         extras = not args.main_loop_only
         fast = os.environ.get('RNR_BENCH_FAST') == '1'      # scripts/stage.sh: headline loop + per-stage figures only
@@ -835,6 +955,11 @@ def main(argv=None):
                 del pe
         if world == 1 and extras and (not fast or os.environ.get('RNR_BENCH_SINGLE') == '1'):
             res['single_view_mode'] = single_view_block(sc, args, dev)
+        if world == 1 and extras and not fast and not args.no_dropin_loop:
+            try:
+                res['dropin_view_loop'] = dropin_view_loop_block(sc, args, dev)
+            except Exception as e:          # noqa: BLE001 - an extra must never fail the bench line
+                res['dropin_view_loop'] = {'error': repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             last_id = int(ids[(args.warmup + args.steps - 1) * V + V - 1])
             hip_last = None if args.no_parity else last_frame

@@ -293,9 +293,12 @@ typedef struct rnr_conv_desc {
 #define RNR_CONV_WINOGRAD 8
 /* (with RNR_CONV_WINOGRAD) F(4x4, 3x3) for the 3x3 convolutions whose maps tile into 32 x 16 pixels, whose columns into 64s and
  * whose grid fills the chip: 36 multiplications per 4 x 4 outputs (2.25 per output; F(2x2, 3x3): 4, direct: 9) on the
- * interpolation points (0, +-3/4, +-3/2, inf).  Opt-in: the larger transforms (coefficients up to 3.375) put the rounding
- * error at ~4.5 x the direct form's (rms; F(2x2, 3x3): 1.3 x) — scripts/experiments/winograd_accuracy_study.py,
- * tests/test_gpu_unet.py.  The F(4x4, 3x3) weight image is stored behind the F(2x2, 3x3) one (both flags when packing AND
+ * interpolation points (0, +-3/4, +-3/2, inf).  A flag of its own because the larger transforms (coefficients up to 3.375) put the
+ * rounding error at ~4.5 x the direct form's (rms; F(2x2, 3x3): 1.3 x) — scripts/experiments/winograd_accuracy_study.py,
+ * tests/test_gpu_unet.py: <= 1e-4 of the output peak against a float64 convolution on every U-Net layer shape.  The Python host
+ * layer (rnr_amd.unet.UNetPlan) sets it BY DEFAULT since r04 (conv_algo 'winograd4'); a C caller chooses per descriptor.
+ * Non-finite inputs: an inf / NaN activation reaches every output of the 4 x 4 tiles whose 6 x 6 input patch contains it
+ * (F(2x2, .): 2 x 2 tiles of a 4 x 4 patch; direct: the outputs whose window contains it).  The F(4x4, 3x3) weight image is stored behind the F(2x2, 3x3) one (both flags when packing AND
  * convolving); shapes it does not cover run F(2x2, 3x3) / direct from the same buffer.  rnr_conv_algorithm reports 4. */
 #define RNR_CONV_WINOGRAD4 16
 

@@ -2308,6 +2308,10 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
         else { if (f16) launch_halo_emu<1, 2>(pl, grid, P, st); else launch_halo_emu<0, 2>(pl, grid, P, st); }
     }
     else if (pl.wino) {
+        // the Winograd kernels run their last chunk unconditionally and give every slice ceil(chunks / splitk) chunks: an empty
+        // trailing slice would stage the wrong range and look ahead past the weight image (make_plan never produces one)
+        RNR_REQUIRE(pl.splitk <= 1 || (long)(pl.splitk - 1) * ((pl.chunks_per_tap + pl.splitk - 1) / pl.splitk) < pl.chunks_per_tap,
+                    "rnr_conv2d: split-K plan with an empty slice (%d chunks cut %d ways)", pl.chunks_per_tap, pl.splitk);
         P.weight_wino = weight_packed + packed_f32_floats(d);
         P.par_inner = 0;
         if (pl.wino == 4) {

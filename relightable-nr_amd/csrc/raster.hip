@@ -474,7 +474,8 @@ raster_tile_kernel(const RasterParams P) {
             }
             __syncthreads();
             const int qn = s_qn;
-            if (qn > QCAP - RTHREADS || w0 + RTHREADS >= wn) {      // block-uniform
+            __syncthreads();        // every wave has read s_qn before any wave's next append: the flush decision IS block-uniform
+            if (qn > QCAP - RTHREADS || w0 + RTHREADS >= wn) {
                 process_queue(s_queue, qn);                        // ends with a barrier
                 if (tid == 0) s_qn = 0;
                 __syncthreads();
@@ -521,7 +522,8 @@ raster_tile_kernel(const RasterParams P) {
         if ((step % FLUSH_EVERY) == FLUSH_EVERY - 1 || step == nsteps - 1) {
             __syncthreads();
             const int qn = s_qn;
-            if (qn > 2 * SCAN_CHUNK || step == nsteps - 1) {    // block-uniform
+            __syncthreads();        // as above: no wave appends (next step) before all have read the count
+            if (qn > 2 * SCAN_CHUNK || step == nsteps - 1) {
                 process_queue(s_queue, qn);                    // ends with a barrier
                 if (tid == 0) s_qn = 0;
                 __syncthreads();

@@ -53,7 +53,7 @@ CONV_STATS_PREZEROED = 1
 CONV_F32_EMU_BF16X6 = 2
 CONV_F32_EMU_F16X3 = 4
 CONV_WINOGRAD = 8        # Winograd F(2x2, 3x3) for the 3x3 convolutions (exact-fp32 operands, include/rnr_hip.h)
-CONV_WINOGRAD4 = 16      # with CONV_WINOGRAD: F(4x4, 3x3) where the shape allows (opt-in, include/rnr_hip.h)
+CONV_WINOGRAD4 = 16      # with CONV_WINOGRAD: F(4x4, 3x3) where the shape allows (set by UNetPlan's default conv_algo 'winograd4'; include/rnr_hip.h)
 EMU_FLAGS = {'f32': 0, 'bf16x6': CONV_F32_EMU_BF16X6, 'f16x3': CONV_F32_EMU_F16X3}
 CONV3x3_REFLECT, CONV4x4S2_REFLECT, CONVT4x4S2 = 0, 1, 2
 

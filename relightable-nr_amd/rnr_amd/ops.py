@@ -285,10 +285,10 @@ def rasterize_gbuffer(mesh, v_uvz, pose, image_size, near=0.0, far=1e5, maps=Non
     gb = RnrGbuffer(*[out[m].data_ptr() if m in out else None for m in GBUFFER_MAPS])
     if pose is not None:
         _chk(pose, 'pose')
-    if workspace is None:
-        workspace = torch.empty(L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces, S), dtype=torch.uint8, device=v_uvz.device)
     if prepared and workspace is None:
         raise ValueError('rasterize_gbuffer(prepared=True) needs the workspace frame_prepare cleared')
+    if workspace is None:
+        workspace = torch.empty(L.rnr_gbuffer_workspace_bytes(N, mesh.num_faces, S), dtype=torch.uint8, device=v_uvz.device)
     fn = L.rnr_rasterize_gbuffer_prepared if prepared else L.rnr_rasterize_gbuffer
     check(fn(ctypes.byref(mesh.c), _ptr(v_uvz), _ptr(pose), N, S, float(near), float(far), ctypes.byref(gb), _ptr(workspace),
              _stream()))
@@ -304,6 +304,11 @@ def frame_prepare(mesh, K, pose, image_size, v_uvz=None, tangents=None, lp_basis
     L = _lib.load()
     _chk(K, 'K'); _chk(pose, 'pose')
     N = K.shape[0]
+    # project_vertex<true> strides the poses by 16 floats and reads t from elements 3, 7, 11: anything but [N,4,4] is out of bounds
+    if K.dim() != 3 or tuple(K.shape[1:]) != (3, 3) or tuple(pose.shape) != (N, 4, 4):
+        raise ValueError('frame_prepare: K must be [N,3,3] and pose [N,4,4] (got %s, %s)' % (tuple(K.shape), tuple(pose.shape)))
+    if light_probe is not None and (lp_basis is None or lp_coeff is None):
+        raise ValueError('frame_prepare: light_probe needs lp_basis and lp_coeff')
     for x, n in ((v_uvz, 'v_uvz'), (tangents, 'tangents'), (lp_basis, 'lp_basis'), (lp_coeff, 'lp_coeff'), (light_probe, 'light_probe')):
         if x is not None:
             _chk(x, n)

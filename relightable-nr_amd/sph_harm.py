@@ -20,10 +20,15 @@ def sph2cart(azimuth, elevation, r):
     return r * ce * m.cos(azimuth), r * ce * m.sin(azimuth), r * m.sin(elevation)
 
 
-def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None):
+def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None, as_tensor=False):
     """sph_harm.py:41-71.  directions [n,3] (numpy or tensor) or azi/pol in degrees -> np.ndarray [n,(lmax+1)^2]
     (float64 container like the reference; values carry float32 precision, which is what every caller casts to).
-    Runs on the device of `directions` when that is a GPU tensor, else on `device` (default: the current GPU)."""
+    Runs on the device of `directions` when that is a GPU tensor, else on `device` (default: the current GPU).
+    as_tensor=True (not in the reference): return the float32 DEVICE tensor instead — the per-view loop of test_rnr.py:322-328
+    then needs no host round trip (`sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape(-1, 3), as_tensor=True)`
+    in place of the `.cpu().detach().numpy()` ... `torch.from_numpy(...).to(device)` pair).
+    The numpy result is written by ONE device -> pinned-host copy (converted to float64 on the device): the reference's contract
+    costs a 19 MB transfer per 512 x 512 view, not a pageable copy plus a host-side cast."""
     if directions is None:
         a, p = np.deg2rad(np.asarray(azi, np.float64)), np.deg2rad(np.asarray(pol, np.float64))
         directions = np.stack([np.sin(p) * np.cos(a), np.sin(p) * np.sin(a), np.cos(p)], -1)
@@ -32,8 +37,13 @@ def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None):
     else:
         dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         src = directions.detach().cpu().numpy() if torch.is_tensor(directions) else directions
-        d = torch.as_tensor(np.asarray(src, np.float32)).contiguous().to(dev)
-    return ops.sh_basis(d, int(lmax)).cpu().numpy().astype(np.float64)
+        d = torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32)).to(dev)
+    out = ops.sh_basis(d, int(lmax))
+    if as_tensor:
+        return out
+    host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)     # a block of torch's caching pinned allocator
+    host.copy_(out)                                                         # device-side cast + one D2H copy, blocking
+    return host.numpy()                                                     # the array keeps the pinned block alive
 
 
 def fit_sh_coeff(samples, sh_basis_val):

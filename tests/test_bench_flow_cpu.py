@@ -39,6 +39,17 @@ def test_bench_control_flow_world2_gloo(V, steps, warm):
     assert res['stub'] is True and res['n_gpus'] == 2 and res['n_ranks_seen'] == 2
     assert res['steps'] == steps and res['warmup'] == warm and res['scaling'] == 'weak'
     assert res['config']['views_per_step_per_gpu'] == V
+    # the multi-GPU line names ITS config: BASELINE configs[3] with the global batch stated, and the exact
+    # configs[3] per-GPU batch timed beside it (the stub stands in with V // 2 views per rank)
+    assert res['config']['global_views_per_step'] == 2 * V
+    assert 'configs[3]' in res['config']['workload'] and 'configs[2]' not in res['config']['workload']
+    assert 'GLOBAL batch = %d views per step' % (2 * V) in res['config']['workload']
+    if V > 1:
+        w8 = res['with_8_views_per_gpu']
+        assert w8['views_per_step_per_gpu'] == max(1, V // 2) and w8['global_views_per_step'] == 2 * max(1, V // 2)
+        assert abs(w8['frames_per_s'] - steps * w8['global_views_per_step'] / (w8['ms_per_step'] * 1e-3 * steps)) < 1e-6 * w8['frames_per_s']
+    else:
+        assert 'with_8_views_per_gpu' not in res
     # value is the whole-job aggregate over both ranks on the MAX-reduced time
     assert abs(res['value'] - steps * 2 * V / (res['ms_per_step'] * 1e-3 * steps)) < 1e-6 * res['value']
     gc = res['gather_check']
@@ -76,6 +87,8 @@ def test_plain_launch_with_gpus_1_is_one_process():
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
     assert res['n_gpus'] == 1 and res['n_ranks_seen'] == 1
+    assert 'configs[2]' in res['config']['workload'] and res['config']['global_views_per_step'] == 2
+    assert 'with_8_views_per_gpu' not in res
 
 
 def test_launcher_world_size_must_equal_gpus():

@@ -92,6 +92,60 @@ def test_rnr_view_loop_with_dropin_modules(golden, tmp_path):
             assert p > 55.0, p
 
 
+@pytest.mark.parametrize('sh_on_device', [False, True])
+def test_rnr_view_loop_at_bench_size(tmp_path, sh_on_device):
+    """Level 1 of INTEGRATION.md AT THE BENCHMARKED SIZE: test_rnr.py:265-377's call sequence through the
+    drop-in modules (rnr_amd.view_loop.DropinViewLoop = network.Rasterizer -> render.get_TBN_map -> camera.get_view_dir_map ->
+    sph_harm.evaluate_sh_basis [numpy in / numpy out, or the one-line device variant] -> TextureMapper -> 2 x RaySampler ->
+    torch.cat -> RenderingNet -> RayRenderer) on bench.py's scene: 65 536-face sphere read back from an OBJ file, 512^2, C = 24,
+    nf0 = 64, SH lighting lmax 10.
+      * face_index_map / alpha EQUAL to RNRPipeline's G-buffer of the same pose and to the oracle on the same projected vertices;
+      * the 108-channel network input equals the fused stage's to 2e-5;
+      * frame vs RNRPipeline.render of the same pose <= 1e-5; frame PSNR vs the oracle >= 60 dB."""
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    from rnr_amd.pipeline import RNRPipeline
+    from rnr_amd.view_loop import DropinViewLoop
+    from test_gpu_frame import _bench_scene
+    S = 512
+    sc = _bench_scene()
+    obj = str(tmp_path / 'sphere65536.obj')
+    scene.write_obj(obj, sc['mesh'])
+    loop = DropinViewLoop(obj, S, sc['textures'], sc['unet_sd'], sc['sh_coeff'], nf0=64, device=DEV, sh_on_device=sh_on_device)
+    assert loop.rasterizer.num_face == 65536 and loop.num_ray_total == 26
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=64,
+                       max_views=1, device=DEV, sh_coeff=sc['sh_coeff'], sh_lmax=10, skip_background_tiles=False)
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    lp_ref = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]
+    for vid in ([111, 640] if not sh_on_device else [37]):
+        views = {k: T(v) for k, v in scene.spiral_views(S, [vid]).items()}
+        dv = {k: v.to(DEV) for k, v in views.items()}
+        keep = {}
+        out = loop.view(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], lighting_idx=0, keep=keep)
+        assert tuple(out.shape) == (1, 3, S, S)
+        ref = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True)
+        last = pipe.last
+        assert torch.equal(keep['face_index_map'], last['gb']['face_index_map'])
+        assert torch.equal(keep['alpha_map'], last['gb']['alpha'])
+        ni = last['net_in'][..., :108].permute(0, 3, 1, 2)
+        assert float((keep['render_net_input'] - ni).abs().max()) <= 2e-5
+        assert float((keep['lp'][0] - lp_ref[0].to(DEV)).abs().max()) <= 2e-5
+        d = float((out - ref).abs().max())
+        assert d <= 1e-5, (vid, d)
+        # oracle, one view per call, on the same projected vertices
+        gb = orc.rasterizer_forward(mesh_t, views['proj'], views['pose'], S, v_uvz_ndc=last['v_uvz'].cpu())
+        assert torch.equal(keep['face_index_map'].cpu(), gb['face_index_map'])
+        sh_in = orc.shade_inputs(gb, views['proj_inv'], views['R_inv'], sc['textures'], sc['pivots_spec'], sc['pivots_diff'], 6)
+        y_ref = orc.unet_forward(sc['unet_sd'], sh_in['net_in'])
+        rays_lt = (y_ref.reshape(1, 26, -1, S, S) * 0.5 + 0.5) * 2.0
+        neural = sh_in['neural_img']
+        ref_img = orc.ray_renderer(neural[:, 3:6], sh_in['rays_uv'], rays_lt, lp_ref, albedo_diffuse=neural[:, :3],
+                                   num_ray_diffuse=13, seperate_albedo=True)[0]
+        p = orc.psnr(out.cpu(), ref_img)
+        assert p >= 60.0, (vid, p)
+
+
 def test_dropin_ops_vs_golden(golden):
     """TextureMapper (any C), RaySampler, RayRenderer, get_TBN_map, get_view_dir_map one by one."""
     import camera

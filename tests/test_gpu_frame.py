@@ -188,6 +188,55 @@ def test_frame512_nf64_vs_oracle(precision):
         assert (one - img8[i:i + 1]).abs().max() <= 1e-5, i
 
 
+def test_frame512_nf64_16_view_plan_vs_oracle():
+    """The plan bench.py's headline actually runs: max_views = 16 at 512^2 / nf0 = 64 / 65 536 faces.  At
+    16 views ELEVEN layers run conv_wino4_kernel — L10 / L13 (16 x 32^2 x 512 -> 512: exactly 256 un-split workgroups) only
+    there — and no layer is split over K.  Checked: the algorithm table of the plan; the 16-view call against the oracle on
+    two of its views (index map / alpha equal on the same projected vertices, frame PSNR >= 60 dB); 16 views in one call ==
+    16 calls of one view to 1e-5 (per-view BatchNorm statistics; the one-view calls run the split-K plans); bit-stable."""
+    import ctypes
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene
+    from rnr_amd.pipeline import RNRPipeline
+    S = 512
+    sc = _bench_scene()
+    pipe = RNRPipeline(sc['mesh'], S, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, nf0=64,
+                       max_views=16, device=DEV, sh_coeff=sc['sh_coeff'], sh_lmax=10, skip_background_tiles=False)
+    algos = [pipe.unet.L.rnr_conv_algorithm(ctypes.byref(st['desc']), 16, *st['in_hw']) for st in pipe.unet.steps]
+    assert pipe.unet.conv_algo == 'winograd4' and len(algos) == 22
+    assert algos.count(4) == 11 and algos.count(2) == 10 and algos.count(3) == 1, algos
+    assert [i + 1 for i, a in enumerate(algos) if a == 4] == [1, 2, 4, 6, 8, 10, 13, 15, 17, 19, 21]      # SURVEY App. A rows
+    ids = [37, 400, 5, 123, 250, 333, 600, 719, 11, 88, 176, 301, 455, 512, 640, 700]
+    views = {k: T(v) for k, v in scene.spiral_views(S, ids).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    r = lambda sl, **kw: pipe.render(dv['proj'][sl], dv['pose'][sl], dv['proj_inv'][sl], dv['R_inv'][sl], **kw)
+    img16 = r(slice(0, 16)).clone()
+    assert torch.equal(img16, r(slice(0, 16)))                       # bit-stable
+    r(slice(0, 16), keep_intermediates=True)
+    last = pipe.last
+    # ---- oracle on views 3 and 12 of the batch, same projected vertices
+    mesh_t = {k: torch.as_tensor(v) for k, v in sc['mesh'].items()}
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    lp = orc.reconstruct_lp(sc['sh_coeff'][0], basis)[None]
+    for i in (3, 12):
+        vi = {k: v[i:i + 1] for k, v in views.items()}
+        gb = orc.rasterizer_forward(mesh_t, vi['proj'], vi['pose'], S, v_uvz_ndc=last['v_uvz'][i:i + 1].cpu())
+        assert torch.equal(last['gb']['face_index_map'][i:i + 1].cpu(), gb['face_index_map'])
+        assert torch.equal(last['gb']['alpha'][i:i + 1].cpu(), gb['alpha'])
+        sh_in = orc.shade_inputs(gb, vi['proj_inv'], vi['R_inv'], sc['textures'], sc['pivots_spec'], sc['pivots_diff'], 6)
+        y_ref = orc.unet_forward(sc['unet_sd'], sh_in['net_in'])
+        rays_lt = (y_ref.reshape(1, 26, -1, S, S) * 0.5 + 0.5) * 2.0
+        neural = sh_in['neural_img']
+        ref_img = orc.ray_renderer(neural[:, 3:6], sh_in['rays_uv'], rays_lt, lp, albedo_diffuse=neural[:, :3],
+                                   num_ray_diffuse=13, seperate_albedo=True)[0]
+        p = orc.psnr(img16[i:i + 1].cpu(), ref_img)
+        assert p >= 60.0, (i, p)
+    # ---- 16 views in one call == 16 one-view calls
+    for i in range(16):
+        one = r(slice(i, i + 1))
+        assert (one - img16[i:i + 1]).abs().max() <= 1e-5, i
+
+
 def test_frame512_conv_algorithms_agree():
     """The gate behind the default conv_algo, as a regression test on six views of the bench
     workload: frames of the F(4x4, 3x3) product path ('winograd4'), of the F(2x2, .)-only path ('winograd') and of the direct

@@ -652,6 +652,8 @@ WINO4_CASES = [
     (1, 64, 64, [512], 512, 4),         # 64 workgroups: F(4x4, 3x3) split four ways over K (partial outputs + splitk_reduce_kernel + finalise)
     (1, 128, 128, [256], 256, 4),       # 128 workgroups: split two ways
     (16, 32, 32, [272], 128, 4),        # 64 workgroups x 17 chunks: four slices of 5, 5, 5, 2 chunks (the last one short)
+    (16, 32, 32, [512], 512, 4),        # L10 / L13 of the 16-view bench plan: exactly 256 UN-SPLIT workgroups, 32 chunks
+    (16, 64, 64, [512], 512, 4),        # L8 / L15 at 16 views: 1024 workgroups, 32 chunks, 8 column tiles
 ]
 
 
