@@ -1709,9 +1709,20 @@ pack_weight_emu_kernel(rnr_conv_desc d, const float* __restrict__ w, char* __res
         packed[(((chunk * NT + t) * 2 + (k >> 3)) * (long)wstride + co) * 8 + (k & 7)] = (unsigned short)(term[t] & 0xffffu);
 }
 
+#ifndef WINO_OUT_AUX
+#define WINO_OUT_AUX 0           // cache policy of the Winograd kernels' output stores (aux operand: 0 default, 2 = nt / streaming)
+#endif
 #include "conv_wino.inc"
 #include "conv_wino80.inc"
 #include "conv_wino2.inc"
+#ifndef W2_PAIRS
+#define W2_PAIRS 2            // bit 1: conv_wino2p_kernel (K-step pairs, r05) runs the TRANSPOSED 4x4 stride-2 layers (-4.3 ... -4.7 %), bit 0:
+                              // ... the stride-2 convolutions too (measured + 8 ... + 23 %: the kernel needs scratch there and its 12-MFMA weight
+                              // look-ahead stalls behind the two HBM halo loads of every phase block; profiles/r05_wino2_pairs_ab.txt); the
+                              // others run conv_wino2_kernel (r03 / r04)
+#endif
+#define W2_PAIRS_KIND(kind) ((kind) == RNR_CONVT4x4S2 ? ((W2_PAIRS) & 2) != 0 : ((W2_PAIRS) & 1) != 0)
+#include "conv_wino2p.inc"
 #include "conv_wino4.inc"
 
 // mask[tile] = any(alpha > 0) over the tw x th output pixels of the tile (tile order = the halo kernels' mt index)
@@ -2031,9 +2042,15 @@ static size_t wino_weight_floats(const rnr_conv_desc* d) {       // 0: this conv
     if (d->kind == RNR_CONV3x3_REFLECT && d->c_out_pad == 80) return (npairs / 2 + W80_BDIST) * W80_STEP_FLOATS;
     if (d->kind == RNR_CONV3x3_REFLECT)
         return d->c_out_pad % WINO_BN ? 0 : (size_t)(d->c_out_pad / WINO_BN) * (npairs + WINO_BDIST) * WINO_STEP_FLOATS;
-    if (d->kind == RNR_CONVT4x4S2)
-        return d->c_out_pad % 64 ? 0 : (size_t)(d->c_out_pad / 64) * (npairs + W2_BDIST) * w2_step_floats<2>();
-    return d->c_out_pad % 128 ? 0 : (size_t)(d->c_out_pad / 128) * (4 * npairs + W2_BDIST) * w2_step_floats<1>();     // four phases
+    // pair layout (conv_wino2p.inc): npairs K steps = npairs / 2 pair-steps per phase, + the look-ahead padding
+    if (d->kind == RNR_CONVT4x4S2) {
+        if (d->c_out_pad % 64) return 0;
+        return W2_PAIRS_KIND(RNR_CONVT4x4S2) ? (size_t)(d->c_out_pad / 64) * (npairs / 2 + W2P_PAD_PAIRS) * w2p_pair_floats<2>()
+                                             : (size_t)(d->c_out_pad / 64) * (npairs + W2_BDIST) * w2_step_floats<2>();
+    }
+    if (d->c_out_pad % 128) return 0;
+    return W2_PAIRS_KIND(RNR_CONV4x4S2_REFLECT) ? (size_t)(d->c_out_pad / 128) * (4 * (npairs / 2) + W2P_PAD_PAIRS) * w2p_pair_floats<1>()
+                                                : (size_t)(d->c_out_pad / 128) * (4 * npairs + W2_BDIST) * w2_step_floats<1>();     // four phases
 }
 static size_t wino4_weight_floats(const rnr_conv_desc* d) {      // 0: this convolution has no F(4x4, 3x3) image
     if (!(d->flags & RNR_CONV_WINOGRAD) || !(d->flags & RNR_CONV_WINOGRAD4) || d->kind != RNR_CONV3x3_REFLECT ||
@@ -2089,8 +2106,8 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
             hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
                                weight, packed + total, nw);
         else
-            hipLaunchKernelGGL(pack_weight_wino2_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
-                               weight, packed + total, nw);
+            hipLaunchKernelGGL(W2_PAIRS_KIND(d->kind) ? pack_weight_wino2p_kernel : pack_weight_wino2_kernel,
+                               dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, as_stream(stream), *d, weight, packed + total, nw);
         if (int e = check_launch("pack_weight_wino_kernel")) return e;
         if (const long nw4 = (long)wino4_weight_floats(d)) {
             hipLaunchKernelGGL(pack_weight_wino4_kernel, dim3((unsigned)((nw4 + 255) / 256)), dim3(256), 0, as_stream(stream), *d,
@@ -2320,8 +2337,13 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
         }
         else if (pl.wino == 1) launch_wino(dim3((unsigned)grid_wgs), P, st);
         else if (pl.wino == 3) launch_wino80(dim3((unsigned)grid_wgs), P, st);
-        else if (d->kind == RNR_CONV4x4S2_REFLECT) launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
-        else launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);
+        else if (d->kind == RNR_CONV4x4S2_REFLECT) {
+            if (W2_PAIRS_KIND(RNR_CONV4x4S2_REFLECT)) launch_wino2p<1>(dim3((unsigned)grid_wgs), P, st);
+            else launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
+        } else {
+            if (W2_PAIRS_KIND(RNR_CONVT4x4S2)) launch_wino2p<2>(dim3((unsigned)grid_wgs), P, st);
+            else launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);
+        }
     }
     else if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
     else if (pl.halo && d->kind == RNR_CONV4x4S2_REFLECT) launch_halo<1>(pl, P, st);

@@ -101,10 +101,28 @@ class Rasterizer(nn.Module):
         renderer.fill_back = False
         self.renderer = renderer
         self._mesh = {}
+        self._static = {}
 
     def _apply(self, fn, *a, **k):
         self._mesh = {}
+        self._static = {}
         return super()._apply(fn, *a, **k)
+
+    def _static_outputs(self, fill_back, device):
+        """The entries of the 14-tuple that do not depend on the camera (faces_v_idx, faces_v, faces_vt: gathers of the mesh
+        buffers the reference redoes per call, network.py:183-198) and mesh_span on the device (a per-call `.to(device)` of a
+        CPU scalar is a pageable copy that drains the stream): computed once per (fill_back, device), reset by .to() / .cuda()."""
+        # in-place edits of the mesh buffers bump their version counters: a stale gather is never returned
+        key = (fill_back, str(device)) + tuple((t.data_ptr(), t._version) for t in
+                                                (self.vertices, self.faces, self.vertices_texcoords, self.faces_vt_idx))
+        if key not in self._static:
+            self._static.clear()
+            faces_v_idx = self._both_sides(self.faces) if fill_back else self.faces
+            faces_v = nr.vertex_attrs_to_faces(self.vertices, faces_v_idx)
+            faces_vt = nr.vertex_attrs_to_faces(self.vertices_texcoords,
+                                                self._both_sides(self.faces_vt_idx) if fill_back else self.faces_vt_idx)
+            self._static[key] = (faces_v_idx, faces_v, faces_vt, self.mesh_span.to(device) * 5e-3)
+        return self._static[key]
 
     @staticmethod
     def _both_sides(idx):
@@ -141,11 +159,8 @@ class Rasterizer(nn.Module):
         v_uvz[..., 0] = (v_uvz[..., 0] * 0.5 + 0.5) * S
         v_uvz[..., 1] = (1 - (v_uvz[..., 1] * 0.5 + 0.5)) * S
         v_depth = misc.interpolate_bilinear(depth[0, :, :, None].contiguous(), v_uvz[..., 0], v_uvz[..., 1])
-        v_front_mask = ((v_uvz[0, :, 2] - v_depth[0, :, 0]) < self.mesh_span.to(depth.device) * 5e-3)[None, :]
-        faces_v_idx = self._both_sides(self.faces) if fill_back else self.faces
-        faces_v = nr.vertex_attrs_to_faces(self.vertices, faces_v_idx)
-        faces_vt = nr.vertex_attrs_to_faces(self.vertices_texcoords,
-                                            self._both_sides(self.faces_vt_idx) if fill_back else self.faces_vt_idx)
+        faces_v_idx, faces_v, faces_vt, span_eps = self._static_outputs(fill_back, depth.device)
+        v_front_mask = ((v_uvz[0, :, 2] - v_depth[0, :, 0]) < span_eps)[None, :]
         return (gb['uv_map'], gb['alpha'], gb['face_index_map'], gb['weight_map'][..., None], faces_v_idx, gb['normal_map'],
                 gb['normal_map_cam'], faces_v, faces_vt, gb['position_map'], gb['position_map_cam'], depth[..., None],
                 v_uvz, v_front_mask)

@@ -7,6 +7,8 @@ Nothing here is fused: every call below is one of the reference's own calls, wit
 (TBN_map [N,H,W,3,3], rays_dir [N,H,W,3,13], the 113 MB torch.cat of test_rnr.py:349-356 ...).  The fused form of the same
 frame is rnr_amd.pipeline.RNRPipeline (Level 2).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -69,7 +71,7 @@ class DropinViewLoop:
             if type(m) == torch.nn.BatchNorm2d:
                 m.train()
 
-    def view(self, proj, pose, proj_inv, R_inv, lighting_idx=0, events=None, keep=None):
+    def view(self, proj, pose, proj_inv, R_inv, lighting_idx=0, events=None, keep=None, host_times=None):
         """One iteration of test_rnr.py:265-377 for device tensors proj / proj_inv / R_inv [1,3,3], pose [1,4,4]:
         -> outputs_final [1,3,S,S].  events: list that receives (stage, torch.cuda.Event) at the stage boundaries (STAGES);
         keep: dict that receives the intermediate maps parity tests compare."""
@@ -83,6 +85,10 @@ class DropinViewLoop:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 events.append((name, e))
+            if host_times is not None:          # diagnosis only: host wall clock at the boundary, device drained first (unless .drain is off)
+                if getattr(self, 'drain', True):
+                    torch.cuda.synchronize()
+                host_times.append((name, time.perf_counter()))
         with torch.no_grad():
             mark('start')
             # rasterize (test_rnr.py:282-295)
@@ -106,8 +112,16 @@ class DropinViewLoop:
                 sh_basis_map = sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape((-1, 3)), as_tensor=True) \
                     .reshape((*(view_dir_map.shape[:3]), -1))
             else:
-                sh_basis_map = sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape((-1, 3)).cpu().detach().numpy()) \
-                    .reshape((*(view_dir_map.shape[:3]), -1)).astype(np.float32)      # [N, H, W, 9]
+                if host_times is None:
+                    sh_basis_map = sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape((-1, 3)).cpu().detach().numpy()) \
+                        .reshape((*(view_dir_map.shape[:3]), -1)).astype(np.float32)      # [N, H, W, 9]
+                else:       # the same expression, statement by statement, for the host-time breakdown
+                    d_np = view_dir_map.reshape((-1, 3)).cpu().detach().numpy()
+                    mark('sh: .cpu().detach().numpy()')
+                    b64 = sph_harm.evaluate_sh_basis(lmax=2, directions=d_np)
+                    mark('sh: evaluate_sh_basis')
+                    sh_basis_map = b64.reshape((*(view_dir_map.shape[:3]), -1)).astype(np.float32)
+                    mark('sh: .astype(np.float32)')
                 sh_basis_map = torch.from_numpy(sh_basis_map).to(device)
             mark('evaluate_sh_basis(+host)')
             # sample texture (test_rnr.py:333-336)

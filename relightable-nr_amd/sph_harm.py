@@ -28,7 +28,7 @@ def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None, 
     then needs no host round trip (`sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape(-1, 3), as_tensor=True)`
     in place of the `.cpu().detach().numpy()` ... `torch.from_numpy(...).to(device)` pair).
     The numpy result is written by ONE device -> pinned-host copy (converted to float64 on the device): the reference's contract
-    costs a 19 MB transfer per 512 x 512 view, not a pageable copy plus a host-side cast."""
+    costs a 19 MB transfer per 512 x 512 view (0.4 ms), not a pageable copy plus a host-side cast."""
     if directions is None:
         a, p = np.deg2rad(np.asarray(azi, np.float64)), np.deg2rad(np.asarray(pol, np.float64))
         directions = np.stack([np.sin(p) * np.cos(a), np.sin(p) * np.sin(a), np.cos(p)], -1)
@@ -42,7 +42,10 @@ def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None, 
     if as_tensor:
         return out
     host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)     # a block of torch's caching pinned allocator
-    host.copy_(out)                                                         # device-side cast + one D2H copy, blocking
+    # cast on the DEVICE first, then a same-dtype blocking D2H copy: `host.copy_(out)` with float32 -> float64 across devices
+    # takes torch's slow conversion path (measured in the drop-in loop at 512^2: 15.6 ms per call against 0.37 ms this way,
+    # scripts/exp_dropin_host2.py)
+    host.copy_(out.double())
     return host.numpy()                                                     # the array keeps the pinned block alive
 
 

@@ -40,3 +40,39 @@ tbn = torch.randn(1, S, S, 3, 3, device=dev)
 out['user: torch.matmul(TBN^T, view_dir) + normalize (test_rnr.py:314-315)'], _ = med(lambda: torch.nn.functional.normalize(torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), vd.reshape((-1, 3, 1)))[..., 0].reshape(vd.shape), dim=-1))
 import json
 print(json.dumps(out, indent=1))
+
+# ---- the same statements INSIDE the drop-in loop at the bench configuration: host wall clock per stage (device drained at
+# every boundary), median over 20 views
+import tempfile
+from rnr_amd import scene
+from rnr_amd.view_loop import DropinViewLoop
+sys.path.insert(0, ROOT)
+import bench
+args = bench.parse([])
+sc = bench.build_scene(args)
+with tempfile.TemporaryDirectory() as td:
+    obj = os.path.join(td, 'm.obj'); scene.write_obj(obj, sc['mesh'])
+    loop = DropinViewLoop(obj, 512, sc['textures'], sc['unet_sd'], sc['sh_coeff'], nf0=64, device=dev)
+pv = {k: torch.from_numpy(v).to(dev) for k, v in scene.spiral_views(512, np.arange(40)).items()}
+pose = lambda i: (pv['proj'][i:i + 1], pv['pose'][i:i + 1], pv['proj_inv'][i:i + 1], pv['R_inv'][i:i + 1])
+for i in range(5):
+    loop.view(*pose(i))
+acc = {}
+for i in range(5, 25):
+    ht = []
+    loop.view(*pose(i), host_times=ht)
+    for (_, t0), (name, t1) in zip(ht[:-1], ht[1:]):
+        acc.setdefault(name, []).append((t1 - t0) * 1e3)
+tab = {k: float(np.median(v)) for k, v in acc.items()}
+tab['SUM'] = float(sum(tab.values()))
+print(json.dumps({'host_ms_per_stage_drained': tab}, indent=1))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(5, 25):
+    loop.view(*pose(i))
+torch.cuda.synchronize(); print('numpy contract, free running: %.2f ms per view' % ((time.perf_counter() - t0) / 20 * 1e3))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for i in range(5, 15):
+    loop.view(*pose(i))
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(25)
