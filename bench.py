@@ -412,7 +412,7 @@ def single_view_block(sc, args, dev):
         'views_per_call': 1, 'views': n1,
         'workload': 'test_rnr.py:265-393: spiral_step720 views in order, one view per call, %dx%d, full HIP RenderingNet' % (args.img_size, args.img_size),
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view; the split-K Winograd layers are '
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2p_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view; the split-K Winograd layers are '
                                                   'followed by a reduce launch and the one-workgroup-per-CU grids by a BatchNorm finalise launch of their own: '
                                                   '12 + 13 launches at 512^2, profiles/r04_frame_timeline_f32_views1.txt; HIP events bracket the U-Net stage of every call)',
                      **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
@@ -731,7 +731,7 @@ def main(argv=None):
                        'views_per_step_per_gpu': V, 'global_views_per_step': world * V,
                        'parallelism': 'views sharded x%d, all_gather of frames' % world,
                        'conv_algo': None if stub else pipe.unet.conv_algo},
-            'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino4_kernel / conv_wino_kernel / conv_wino2_kernel / conv_wino80_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
+            'roofline': {'bound': 'mfma', 'kernel': '%s (%d conv launches/step, BatchNorm finalise inside them; HIP events bracket the U-Net stage)' % ('conv_wino4_kernel / conv_wino2p_kernel / conv_wino2_kernel / conv_wino80_kernel' if args.precision == 'f32' else 'conv_halo_emu_kernel', n_conv),
                          **algo8, 'traffic': traffic,
                          'traffic_unit': 'bytes/step (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
                          **{k: v for k, v in traffic_info.items() if k != 'traffic_path'},

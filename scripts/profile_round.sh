@@ -11,7 +11,10 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-for cfg in f32:16:winograd4 f32:1:winograd4 f32:16:winograd f32:16:direct f16x3:16:direct bf16x6:16:direct; do
+# LITE=1: the product path only (the direct / F(2x2)-only / emulation kernels did not change in the round)
+CFGS="f32:16:winograd4 f32:1:winograd4 f32:16:winograd f32:16:direct f16x3:16:direct bf16x6:16:direct"
+[ "$LITE" = 1 ] && CFGS="f32:16:winograd4 f32:1:winograd4"
+for cfg in $CFGS; do
   prec=${cfg%%:*}; rest=${cfg#*:}; v=${rest%%:*}; algo=${rest##*:}
   name=$prec; [ $prec = f32 ] && [ $algo = direct ] && name=f32_direct; [ $prec = f32 ] && [ $algo = winograd ] && name=f32_f2x2only
   steps=5; [ $v = 1 ] && steps=20
@@ -35,6 +38,7 @@ done
 cp $OUT/${TAG}_pmc_per_kernel_f32_steps2_views1.json $ROOT/profiles/
 for v in 1 8 16; do
   timeout 300 python scripts/layer_time.py --views $v --winograd4 > $OUT/${TAG}_layer_time_f32_views$v.txt 2>&1
+  [ "$LITE" = 1 ] && continue
   timeout 300 python scripts/layer_time.py --views $v --winograd > $OUT/${TAG}_layer_time_f32_f2x2only_views$v.txt 2>&1
   timeout 300 python scripts/layer_time.py --views $v > $OUT/${TAG}_layer_time_f32_direct_views$v.txt 2>&1
 done
