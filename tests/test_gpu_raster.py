@@ -146,6 +146,32 @@ def test_bin_overflow_falls_back_to_scan():
     assert_same(r, g)
 
 
+@pytest.mark.parametrize('S,n_wide,n_plain,seed', [(128, 3000, 1500, 21), (64, 900, 5000, 22)])
+def test_many_wide_faces_flush_path_vs_oracle(S, n_wide, n_plain, seed):
+    """The wide-face list of raster_tile_kernel with FAR more entries than one pass of the workgroup (256) and a candidate queue
+    that fills up: thousands of zero-area faces (two coincident vertices -> exact-only boxes; their pass region is a line through
+    the image, so each one is a candidate of many tiles) between ordinary faces.  ADVICE r04: the flush decision read the queue
+    length without a barrier behind it, so a fast wave could append for the next pass before a slow one had read it and the two
+    took different branches around barriers.  Bit-exact against the oracle, five launches in a row (a barrier mismatch shows as a
+    wrong winner or a hang), batch of 2 with different face sets."""
+    from oracle import raster as oras
+    rng = np.random.RandomState(seed)
+    nf = n_wide + n_plain
+    f = rng.uniform(-1.3, 1.3, size=(2, nf, 3, 3)).astype(np.float32)
+    f[..., 2] = rng.uniform(0.3, 8.0, size=(2, nf, 3))
+    small = rng.rand(2, nf) < 0.6
+    c = f[:, :, :1, :2].copy()
+    f[..., :2] = np.where(small[..., None, None], c + (f[..., :2] - c) * 0.05, f[..., :2])
+    wide = rng.permutation(nf)[:n_wide]
+    f[:, wide, 1] = f[:, wide, 0]                       # coincident vertices: zero area, inf / NaN barycentric inverse
+    f[1, wide[: n_wide // 3], 2, :2] = f[1, wide[: n_wide // 3], 0, :2]     # ... and fully collapsed ones in view 1
+    g = oras.face_index_map(f, S, 0.0, 1e5)
+    for _ in range(5):
+        r = run_hip_raster(f, S, 0.0, 1e5)
+        assert_same(r, g)
+    assert (g['face_index_map'] >= 0).mean() > 0.3
+
+
 def test_sphere_512_vs_oracle():
     """BASELINE config size: 65 536-face UV sphere at 512^2 (includes the zero-area pole faces)."""
     from oracle import raster as oras
@@ -342,6 +368,29 @@ def test_argument_checks():
     f = torch.zeros(1, 4, 3, 3)
     with pytest.raises(RuntimeError):
         ops.forward_face_index_map(f, f, f, f, f, f, 8, 0.0, 1.0, 1, 1, 1)      # CPU tensors are rejected
+
+
+def test_frame_prepare_and_prepared_raster_argument_checks():
+    """frame_prepare strides the poses by 16 floats (a [N,3,4] pose used to project wrongly and read out of bounds),
+    dereferenced lp_basis / lp_coeff without a None check, and rasterize_gbuffer(prepared=True) without the workspace frame_prepare
+    cleared ran on uninitialised counters: all three raise now."""
+    from rnr_amd import ops, scene
+    dev = 'cuda:0'
+    m = scene.uv_sphere(8, 16)
+    dm = ops.DeviceMesh(m['v'], m['vt'], m['vn'], m['f_v_idx'], m['f_vt_idx'], m['f_vn_idx'], dev)
+    v = {k: torch.from_numpy(x).to(dev) for k, x in scene.spiral_views(32, [3, 9]).items()}
+    v_uvz = torch.empty(2, dm.num_vertices, 3, device=dev)
+    with pytest.raises(ValueError, match='pose'):
+        ops.frame_prepare(dm, v['proj'], v['pose'][:, :3].contiguous(), 32, v_uvz=v_uvz)          # [N,3,4]
+    with pytest.raises(ValueError, match='pose'):
+        ops.frame_prepare(dm, v['proj'], v['pose'][:1].contiguous(), 32, v_uvz=v_uvz)             # fewer poses than K
+    with pytest.raises(ValueError, match='lp_basis'):
+        ops.frame_prepare(dm, v['proj'], v['pose'], 32, v_uvz=v_uvz, light_probe=torch.empty(10, 3, device=dev))
+    ops.frame_prepare(dm, v['proj'], v['pose'], 32, v_uvz=v_uvz)                                   # the valid call still works
+    with pytest.raises(ValueError, match='workspace'):
+        ops.rasterize_gbuffer(dm, v_uvz, None, 32, prepared=True)
+    gb = ops.rasterize_gbuffer(dm, v_uvz, None, 32, maps=['face_index_map'])
+    assert int((gb['face_index_map'] >= 0).sum()) > 0
 
 
 def test_gbuffer_vs_reference_module(golden):
