@@ -375,6 +375,14 @@ typedef struct rnr_conv_bn {
     float* scale;       /* [N, c_out_pad] out */
     float* shift;       /* [N, c_out_pad] out */
     float eps;
+    /* torch.nn.BatchNorm2d's train-mode side effect (pytorch_prototyping.py:109, test_rnr.py:229-233 keep the layers in train mode):
+     * running = (1 - momentum) * running + momentum * (batch mean | unbiased batch variance), [c_out] float32, updated in place by
+     * the launch that finalises the statistics.  Statistics are per VIEW in this entry point and torch pools the whole batch, so
+     * the two agree for num_views == 1 only: non-NULL pointers with num_views > 1 are refused (use rnr_conv2d +
+     * rnr_bn_finalize_batch there).  NULL = no update. */
+    float* running_mean;
+    float* running_var;
+    float momentum;
 } rnr_conv_bn;
 size_t rnr_conv_sync_bytes(const rnr_conv_desc* d, int max_views, int in_h, int in_w);
 int rnr_conv2d_fused(const rnr_conv_desc* d, const rnr_conv_src* src0, const rnr_conv_src* src1,

@@ -99,6 +99,7 @@ struct ConvParams {
     unsigned n_arrive;          // arrivals that complete a counter
     const float* gamma; const float* beta; float* scale; float* shift;
     float eps; double count;    // pixels per view behind one statistic
+    float* running_mean; float* running_var; float momentum;     // torch's train-mode side effect, one-view calls only (rnr_conv_bn)
     unsigned* tile_arrive;      // [par * mtiles * ntiles] split-K slices of a tile that have published their slab; NULL = legacy slabs + reduce kernel
     // ---- rnr_conv2d_ray: the U-Net-dependent half of the ray renderer in the out layer's epilogue (80-column configuration) ----
     const float* ray_w;         // [N*OH*OW][c_out_pad] ray weights (rnr_ray_weights); NULL = ordinary epilogue
@@ -219,6 +220,13 @@ __device__ __forceinline__ void bn_finalize_views(const ConvParams& P, int n_fir
             const double g = (double)P.gamma[c] / sqrt(var + (double)P.eps);
             sc = (float)g;
             sf = (float)((double)P.beta[c] - mean * g);
+            // torch.nn.BatchNorm2d in train mode also moves its running statistics (momentum, unbiased variance): the arithmetic
+            // of bn_finalize_batch_kernel; the host passes the buffers for one-view calls only, where per-view = whole batch
+            if (P.running_mean) P.running_mean[c] = (float)((1.0 - (double)P.momentum) * (double)P.running_mean[c] + (double)P.momentum * mean);
+            if (P.running_var) {
+                const double unb = P.count > 1.0 ? var * P.count / (P.count - 1.0) : var;
+                P.running_var[c] = (float)((1.0 - (double)P.momentum) * (double)P.running_var[c] + (double)P.momentum * unb);
+            }
         }
         P.scale[idx] = sc;
         P.shift[idx] = sf;
@@ -2220,6 +2228,9 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
     const bool fused = sync != nullptr;          // rnr_conv2d_fused
     const bool with_bn = fused && bn && bn->gamma;
     if (with_bn) RNR_REQUIRE(bn->beta && bn->scale && bn->shift, "rnr_conv2d_fused: null BatchNorm pointer");
+    if (with_bn) RNR_REQUIRE(!(bn->running_mean || bn->running_var) || num_views == 1,
+                             "rnr_conv2d_fused: running statistics are per-view here; torch pools the batch — pass them for num_views == 1 only (got %d)",
+                             num_views);
     hipStream_t st = as_stream(stream);
     ConvPlan pl;
     make_plan(d, num_views, in_h, in_w, &pl);
@@ -2275,6 +2286,7 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
             P.stats_shard = 2L * num_views * d->c_out_pad;
             P.gamma = bn->gamma; P.beta = bn->beta; P.scale = bn->scale; P.shift = bn->shift;
             P.eps = bn->eps; P.count = (double)pl.OH * pl.OW;
+            P.running_mean = bn->running_mean; P.running_var = bn->running_var; P.momentum = bn->momentum;
             // tickets only where workgroups finish at different times: more than one workgroup per CU (see
             // bn_finalize_shards_kernel); the others get the finalise as a launch of its own
             // (a separate finalise launch for the big Winograd grids too was measured: -0.5 % on seven layers at 8 views — the

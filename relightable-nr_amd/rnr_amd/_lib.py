@@ -45,7 +45,8 @@ class RnrConvDesc(ctypes.Structure):
 
 
 class RnrConvBn(ctypes.Structure):
-    _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('eps', c_float)]
+    _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('eps', c_float),
+                ('running_mean', c_void_p), ('running_var', c_void_p), ('momentum', c_float)]      # NULL / 0: no running-statistics update
 
 
 ACT_NONE, ACT_LRELU02, ACT_RELU = 0, 1, 2

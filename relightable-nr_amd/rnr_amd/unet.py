@@ -106,6 +106,10 @@ class UNetPlan:
         # view and shallow split-K slices meet inside the launch.  'batch_all' (whole-batch statistics, running buffers)
         # keeps the separate rnr_bn_finalize_batch launch; RNR_UNET_UNFUSED=1 runs the separate launches everywhere (A/B).
         self.fused = bn_mode != 'batch_all' and os.environ.get('RNR_UNET_UNFUSED') != '1'
+        # ... except that a ONE-view call of a 'batch_all' plan is the same arithmetic (whole batch = the view): it takes the fused
+        # launches too, the running statistics updated by the launch that finalises the layer (rnr_conv_bn.running_mean / _var;
+        # r05: the drop-in RenderingNet of the reference's one-view loop, 2.65 -> 2.3 ms)
+        self.fused_single = bn_mode == 'batch_all' and os.environ.get('RNR_UNET_UNFUSED') != '1'
         self._tile_mask = None
         self._keep = []
 
@@ -138,7 +142,7 @@ class UNetPlan:
             out.data = torch.empty(self.N, oh, ow, desc.c_out_pad, dtype=torch.float32, device=device)
             step = {'desc': desc, 'packed': packed, 'srcs': srcs, 'out': out, 'in_hw': (s0.h, s0.w), 'bn': None, 'sync': None,
                     'cbn': None}
-            if self.fused:       # arrival counters + statistics shards: zero now, left at zero by every call
+            if self.fused or self.fused_single:       # arrival counters + statistics shards: zero now, left at zero by every call
                 step['sync'] = torch.zeros(self.L.rnr_conv_sync_bytes(ctypes.byref(desc), self.N, s0.h, s0.w),
                                            dtype=torch.uint8, device=device)
             if bn_key is not None and has(bn_key + '.weight') and bn_mode == 'running':
@@ -164,6 +168,10 @@ class UNetPlan:
                             rv.is_cuda and rv.dtype == torch.float32 and rv.is_contiguous()):
                         raise RuntimeError('update_running_stats needs float32 device-resident running buffers')
                     step['bn']['running_mean'], step['bn']['running_var'] = rm, rv      # updated IN PLACE
+                if self.fused_single:
+                    rm, rv = step['bn']['running_mean'], step['bn']['running_var']
+                    step['cbn'] = RnrConvBn(gamma.data_ptr(), beta.data_ptr(), out.scale.data_ptr(), out.shift.data_ptr(), 1e-5,
+                                            rm.data_ptr() if rm is not None else None, rv.data_ptr() if rv is not None else None, 0.1)
             elif bias_key is not None and has(bias_key):
                 b = torch.zeros(desc.c_out_pad, dtype=torch.float32, device=device)
                 b[:c_out] = g(bias_key)
@@ -324,7 +332,7 @@ class UNetPlan:
                                        _ptr(s['packed']), _ptr(ray_w), _ptr(self.out_bias), _ptr(image), n, h, w,
                                        _ptr(mask), st))
                 continue
-            if self.fused:
+            if self.fused or (self.fused_single and n == 1):
                 check(L.rnr_conv2d_fused(ctypes.byref(s['desc']), ctypes.byref(s0), ctypes.byref(s1) if s1 else None,
                                          _ptr(s['packed']), _ptr(out.data), ctypes.byref(s['cbn']) if s['cbn'] else None, n, h, w,
                                          _ptr(self.workspace), self.ws_bytes, _ptr(s['sync']), s['sync'].numel(),
