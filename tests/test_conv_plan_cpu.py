@@ -42,7 +42,7 @@ def test_algorithm_per_layer_of_the_benchmark_network():
                                                (2, 64, (128, 128), 64), (0, 64, (64,), 48), (1, 64, (64,), 96)])
 def test_packed_weight_sizes(kind, h, cins, c_out):
     """The Winograd image sits behind the direct one: 16 planes instead of 9 taps (3x3), 9 instead of 4 per parity class
-    (transposed), 4 phases x 9 instead of 16 taps (stride 2), per 64- / 128- / 80-column tile, plus the look-ahead padding;
+    (transposed; K-step pairs since r05), 4 phases x 9 instead of 16 taps (stride 2), per 64- / 128- / 80-column tile, plus the look-ahead padding;
     shapes no Winograd kernel tiles (48 or 96 columns) get no image."""
     L = _lib.load()
     f32 = L.rnr_packed_weight_floats(ctypes.byref(desc(kind, cins, c_out)))
@@ -55,8 +55,8 @@ def test_packed_weight_sizes(kind, h, cins, c_out):
         extra = (ctot // 4 + 2) * 5120
     elif kind == 0:
         extra = 0 if cpad % 64 else (cpad // 64) * (ctot // 2 + 5) * 2048
-    elif kind == 2:
-        extra = 0 if cpad % 64 else (cpad // 64) * (ctot // 2 + 3) * 4608
+    elif kind == 2:     # r05: the pair layout of conv_wino2p_kernel — K steps in pairs of 2 x 4608 floats, one pair of look-ahead padding
+        extra = 0 if cpad % 64 else (cpad // 64) * (ctot // 4 + 1) * 9216
     else:
         extra = 0 if cpad % 128 else (cpad // 128) * (4 * ctot // 2 + 3) * 2304
     assert wino == f32 + extra
