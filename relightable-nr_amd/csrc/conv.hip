@@ -2349,12 +2349,19 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
         }
         else if (pl.wino == 1) launch_wino(dim3((unsigned)grid_wgs), P, st);
         else if (pl.wino == 3) launch_wino80(dim3((unsigned)grid_wgs), P, st);
+        // (preprocessor, not `if`: only the kernel that runs is instantiated into the library)
         else if (d->kind == RNR_CONV4x4S2_REFLECT) {
-            if (W2_PAIRS_KIND(RNR_CONV4x4S2_REFLECT)) launch_wino2p<1>(dim3((unsigned)grid_wgs), P, st);
-            else launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
+#if (W2_PAIRS) & 1
+            launch_wino2p<1>(dim3((unsigned)grid_wgs), P, st);
+#else
+            launch_wino2<1>(dim3((unsigned)grid_wgs), P, st);
+#endif
         } else {
-            if (W2_PAIRS_KIND(RNR_CONVT4x4S2)) launch_wino2p<2>(dim3((unsigned)grid_wgs), P, st);
-            else launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);
+#if (W2_PAIRS) & 2
+            launch_wino2p<2>(dim3((unsigned)grid_wgs), P, st);
+#else
+            launch_wino2<2>(dim3((unsigned)grid_wgs), P, st);
+#endif
         }
     }
     else if (pl.halo && d->kind == RNR_CONV3x3_REFLECT) launch_halo<0>(pl, P, st);
