@@ -1015,8 +1015,9 @@ ray_renderer_api_kernel(const RayApiParams P) {
 }
 
 // ---- layout helpers --------------------------------------------------------------------------------
+// one element per thread: the form for channel counts whose 64-pixel tile does not fit 64 KB of LDS (c_pad > 240)
 __global__ void __launch_bounds__(256)
-nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int hw, int c_pad, long total) {
+nchw_to_nhwc_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int hw, int c_pad, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*hw*c_pad
     if (i >= total) return;
     const int ch = (int)(i % c_pad);
@@ -1024,10 +1025,9 @@ nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c
     const long n = np / hw, p = np % hw;
     out[i] = ch < c ? in[(n * c + ch) * hw + p] : 0.0f;
 }
-
 __global__ void __launch_bounds__(256)
-nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ bias,
-                    int apply_tanh, int c, int hw, int c_pad, long total) {
+nhwc_to_nchw_wide_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ bias,
+                         int apply_tanh, int c, int hw, int c_pad, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over n*c*hw (output order)
     if (i >= total) return;
     const long p = i % hw;
@@ -1038,6 +1038,54 @@ nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, const
     if (bias) v += bias[ch];
     if (apply_tanh) v = tanhf(v);
     out[i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int hw, int c_pad, long total) {
+    // r05: through an LDS tile of 64 pixels x c_pad channels — reads coalesced along the pixels of a channel (NCHW rows), writes
+    // coalesced along the channels of a pixel (the one-element-per-thread form reads with a stride of hw floats: 0.143 ms for the
+    // 108-channel network input at 512^2, the layout change in front of the drop-in RenderingNet)
+    extern __shared__ float lt_tile[];          // [c_pad][65]
+    const long pix0 = (long)blockIdx.x * 64;    // over n * hw (hw is a multiple of 64 or the tail is masked)
+    const long npix = total / c_pad;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long pp = pix0 + lane;
+    const long n = pp / hw, p = pp % hw;
+    for (int ch = w; ch < c_pad; ch += 4)
+        lt_tile[ch * 65 + lane] = (ch < c && pp < npix) ? in[(n * c + ch) * hw + p] : 0.0f;
+    __syncthreads();
+    const int per = 64 * c_pad;
+    float* dst = out + pix0 * c_pad;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int px = i / c_pad, ch = i - px * c_pad;
+        if (pix0 + px < npix) dst[i] = lt_tile[ch * 65 + px];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ bias,
+                    int apply_tanh, int c, int hw, int c_pad, long total) {
+    // the reverse through the same tile: reads coalesced along the channels of a pixel, writes along the pixels of a channel
+    extern __shared__ float lt_tile[];          // [c_pad][65]
+    const long npix = total / c;                // total = n * c * hw
+    const long pix0 = (long)blockIdx.x * 64;
+    const int per = 64 * c_pad;
+    const float* src = in + pix0 * c_pad;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int px = i / c_pad, ch = i - px * c_pad;
+        if (pix0 + px < npix) lt_tile[ch * 65 + px] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long pp = pix0 + lane;
+    if (pp >= npix) return;
+    const long n = pp / hw, p = pp % hw;
+    for (int ch = w; ch < c; ch += 4) {
+        float v = lt_tile[ch * 65 + lane];
+        if (bias) v += bias[ch];
+        if (apply_tanh) v = tanhf(v);
+        out[(n * c + ch) * hw + p] = v;
+    }
 }
 
 }  // namespace rnr
@@ -1305,8 +1353,13 @@ extern "C" int rnr_resize_area(const float* src, float* dst, int src_h, int src_
 extern "C" int rnr_nchw_to_nhwc(const float* in, float* out, int n, int c, int h, int w, int c_pad, void* stream) {
     RNR_REQUIRE(in && out && n > 0 && c > 0 && c_pad >= c, "rnr_nchw_to_nhwc: bad arguments");
     const long total = (long)n * h * w * c_pad;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       in, out, c, h * w, c_pad, total);
+    const long npix = (long)n * h * w;
+    if (c_pad <= 240)       // 64-pixel x c_pad tile in LDS (<= 62.4 KB)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), (size_t)c_pad * 65 * sizeof(float),
+                           as_stream(stream), in, out, c, h * w, c_pad, total);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_wide_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           in, out, c, h * w, c_pad, total);
     return check_launch("nchw_to_nhwc_kernel");
 }
 
@@ -1314,8 +1367,13 @@ extern "C" int rnr_nhwc_to_nchw(const float* in, float* out, const float* bias, 
                                 int h, int w, int c_pad, void* stream) {
     RNR_REQUIRE(in && out && n > 0 && c > 0 && c_pad >= c, "rnr_nhwc_to_nchw: bad arguments");
     const long total = (long)n * c * h * w;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       in, out, bias, apply_tanh, c, h * w, c_pad, total);
+    const long npix = (long)n * h * w;
+    if (c_pad <= 240)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), (size_t)c_pad * 65 * sizeof(float),
+                           as_stream(stream), in, out, bias, apply_tanh, c, h * w, c_pad, total);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_wide_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           in, out, bias, apply_tanh, c, h * w, c_pad, total);
     return check_launch("nhwc_to_nchw_kernel");
 }
 

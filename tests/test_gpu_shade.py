@@ -245,3 +245,23 @@ def test_ray_render_background_workgroups_write_exact_zeros():
     assert torch.isfinite(out).all() and torch.equal(out, ref)
     assert float(out.permute(0, 2, 3, 1)[bg.to(DEV)].abs().max()) == 0.0
     assert float(out.permute(0, 2, 3, 1)[(~bg).to(DEV)].abs().max()) > 0.05
+
+
+@pytest.mark.parametrize('n,c,h,w,c_pad', [(1, 108, 64, 64, 112), (3, 30, 20, 13, 32), (2, 78, 16, 24, 80), (1, 3, 7, 9, 16), (2, 250, 8, 8, 256)])
+def test_layout_ops_vs_torch_permute(n, c, h, w, c_pad):
+    """rnr_nchw_to_nhwc / rnr_nhwc_to_nchw (the layout changes around the drop-in RenderingNet; LDS-tiled since r05, the
+    one-element-per-thread form for > 240 channels): exact copies, zero padding channels, bias + tanh on the way back; views
+    whose pixel count is not a multiple of the 64-pixel tile, tiles that straddle two views."""
+    from rnr_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = torch.randn(n, c, h, w, generator=g)
+    y = ops.nchw_to_nhwc(x.to(DEV), c_pad).cpu()
+    assert tuple(y.shape) == (n, h, w, c_pad)
+    assert torch.equal(y[..., :c], x.permute(0, 2, 3, 1)) and float(y[..., c:].abs().sum()) == 0.0
+    raw = torch.randn(n, h, w, c_pad, generator=g)
+    b = torch.randn(c_pad, generator=g)
+    z = ops.nhwc_to_nchw(raw.to(DEV), c, bias=b.to(DEV), apply_tanh=True).cpu()
+    ref = torch.tanh(raw[..., :c] + b[:c]).permute(0, 3, 1, 2)
+    assert tuple(z.shape) == (n, c, h, w) and float((z - ref).abs().max()) <= 2e-6
+    z0 = ops.nhwc_to_nchw(raw.to(DEV), c).cpu()
+    assert torch.equal(z0, raw[..., :c].permute(0, 3, 1, 2))
