@@ -1014,6 +1014,83 @@ ray_renderer_api_kernel(const RayApiParams P) {
     if (P.ltt_diff) P.ltt_diff[i] = ld;
 }
 
+// The same operator for <= 4 colour channels (the repo's probes have 3): a workgroup owns 64 consecutive pixels; thread (pixel lane,
+// ray quarter q) takes the rays q, q + 4, ... of its pixel for ALL channels — the taps of a (pixel, ray) are computed once, rays_lt /
+// rays_color are touched along the pixels (128-byte rows per wave instruction), the uv rows come through an LDS tile (row stride
+// 2 R + 1: conflict-free) — and the four partial sums of a pixel meet in LDS.  Sums over the rays are four interleaved partial
+// sums instead of one chain: <= 1e-6 from the one-thread-per-(channel, pixel) form above (which reads uv with a stride of 2 R floats
+// and recomputes the taps per channel).
+__global__ void __launch_bounds__(256)
+ray_renderer_api_tiled_kernel(const RayApiParams P) {
+    extern __shared__ float ra_sm[];
+    const int R = P.R, C = P.C, n_spec = P.R - P.n_diff;
+    const long pix0 = (long)blockIdx.x * 64;
+    const int valid = (int)min((long)64, P.npix - pix0);
+    const int lane = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const int urow = 2 * R + 1;
+    for (int i = threadIdx.x; i < valid * 2 * R; i += 256) {
+        const int px = i / (2 * R), k = i - px * 2 * R;
+        ra_sm[px * urow + k] = P.rays_uv[pix0 * 2 * R + i];
+    }
+    __syncthreads();
+    const long pix = pix0 + lane;
+    const bool live = lane < valid;
+    const long n = live ? pix / P.hw : 0, p = live ? pix % P.hw : 0;
+    const float* lp = P.lp + (P.lp_n == 1 ? 0 : (size_t)n * P.lp_h * P.lp_w * C);
+    float ss[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        for (int r = qtr; r < R; r += 4) {
+            const float u = ra_sm[lane * urow + r], v = ra_sm[lane * urow + R + r];
+            const float x = fminf(u * (float)P.lp_w, (float)(P.lp_w - 1));
+            const float y = fminf(v * (float)P.lp_h, (float)(P.lp_h - 1));
+            const Taps t = bilinear_taps(x, y, P.lp_w, P.lp_h);
+            const float* l00 = lp + ((size_t)t.y0 * P.lp_w + t.x0) * C;
+            const float* l10 = lp + ((size_t)t.y1 * P.lp_w + t.x0) * C;
+            const float* l01 = lp + ((size_t)t.y0 * P.lp_w + t.x1) * C;
+            const float* l11 = lp + ((size_t)t.y1 * P.lp_w + t.x1) * C;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (c >= C) break;
+                const float col = (l00[c] * P.lp_scale) * t.w00 + (l10[c] * P.lp_scale) * t.w10 + (l01[c] * P.lp_scale) * t.w01 +
+                                  (l11[c] * P.lp_scale) * t.w11;
+                const size_t li = (((size_t)n * R + r) * C + c) * P.hw + p;
+                if (P.rays_color) P.rays_color[li] = col;
+                const float prod = P.rays_lt[li] * col;
+                if (r < n_spec) ss[c] += prod; else sd[c] += prod;
+            }
+        }
+    }
+    __syncthreads();        // the uv tile is dead: the partial sums take its place, [quarter][spec | diff][channel][lane]
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        ra_sm[((qtr * 2 + 0) * 4 + c) * 64 + lane] = ss[c];
+        ra_sm[((qtr * 2 + 1) * 4 + c) * 64 + lane] = sd[c];
+    }
+    __syncthreads();
+    const int c = qtr;      // thread (lane, c) finishes channel c of its pixel
+    if (!live || c >= C) return;
+    float s_spec = 0.f, s_diff = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+        s_spec += ra_sm[((q4 * 2 + 0) * 4 + c) * 64 + lane];
+        s_diff += ra_sm[((q4 * 2 + 1) * 4 + c) * 64 + lane];
+    }
+    const long i = (n * C + c) * P.hw + p;
+    const float ls = s_spec / (float)n_spec;
+    const float as = P.alb_spec[i];
+    const float os = P.no_albedo ? ls : as * ls;
+    float ld = 0.f, od = 0.f;
+    if (P.n_diff > 0) {
+        ld = s_diff / (float)P.n_diff;
+        od = P.no_albedo ? ld : ((P.separate && P.alb_diff) ? P.alb_diff[i] : as) * ld;
+    }
+    P.out[i] = os + od;
+    if (P.out_spec) P.out_spec[i] = os;
+    if (P.out_diff) P.out_diff[i] = od;
+    if (P.ltt_spec) P.ltt_spec[i] = ls;
+    if (P.ltt_diff) P.ltt_diff[i] = ld;
+}
+
 // ---- layout helpers --------------------------------------------------------------------------------
 // one element per thread: the form for channel counts whose 64-pixel tile does not fit 64 KB of LDS (c_pad > 240)
 __global__ void __launch_bounds__(256)
@@ -1445,6 +1522,13 @@ extern "C" int rnr_ray_renderer(const float* rays_uv, const float* rays_lt, cons
     P.out = out; P.out_spec = out_specular; P.out_diff = out_diffuse; P.ltt_spec = ltt_specular; P.ltt_diff = ltt_diffuse;
     P.rays_color = rays_color; P.npix = (long)num_views * height * width; P.hw = height * width;
     const long total = P.npix * channels;
-    hipLaunchKernelGGL(ray_renderer_api_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), P);
+    if (channels <= 4 && num_rays <= 64) {
+        // r05: 64 pixels per workgroup, (pixel, ray quarter) per thread: uv rows staged through LDS, taps once per (pixel, ray) for
+        // all channels, every global access coalesced along the pixels (0.48 -> ms per 512^2 view in the drop-in loop)
+        const size_t lds = sizeof(float) * (size_t)std::max(64 * (2 * num_rays + 1), 4 * 2 * 4 * 64);
+        hipLaunchKernelGGL(ray_renderer_api_tiled_kernel, dim3((unsigned)((P.npix + 63) / 64)), dim3(256), lds, as_stream(stream), P);
+    } else {
+        hipLaunchKernelGGL(ray_renderer_api_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), P);
+    }
     return check_launch("ray_renderer_api_kernel");
 }
