@@ -58,8 +58,18 @@ class TextureMapper(nn.Module):
 
     def forward(self, uv_map, sh_basis_map=None, sh_start_ch=3):
         """uv_map [N,H,W,2], sh_basis_map [N,H,W,9] -> [N,C,H,W] (network.py:67-91)."""
-        sh = sh_basis_map.float().contiguous() if (bool(self.apply_sh) and sh_basis_map is not None) else None
+        sh = sh_basis_map.float().contiguous() if (sh_basis_map is not None and self._apply_sh_flag()) else None
         return ops.texture_mapper([p.detach() for p in self.textures], uv_map.float().contiguous(), sh, sh_start_ch)
+
+    def _apply_sh_flag(self):
+        """bool(self.apply_sh) without a device -> host read per call: the buffer lives on the GPU after `.to(device)` and the
+        reference's `if self.apply_sh` (network.py:84) drains the stream once per view.  Cached per (storage, version): an in-place
+        change or a load_state_dict is seen."""
+        t = self.apply_sh
+        key = (t.data_ptr(), t._version)
+        if getattr(self, '_apply_sh_key', None) != key:
+            self._apply_sh_key, self._apply_sh_val = key, bool(t)
+        return self._apply_sh_val
 
     def flatten_mipmap(self, start_ch, end_ch):
         """network.py:93-99 (init-time / visualisation helper)."""

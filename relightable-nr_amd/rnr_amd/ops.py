@@ -515,6 +515,24 @@ def tbn_map(normal_map, face_index_map, tangents):
     return out
 
 
+_HOST_COPIES = {}
+
+
+def _host_copy(t):
+    """float32 CPU copy of a small constant tensor (ray pivots), cached per (storage, version): `.cpu()` on a device buffer is a
+    blocking copy — one stream drain per call in the reference's per-view loop (two per view for the two ray samplers)."""
+    if not t.is_cuda:
+        return t.detach().contiguous().float()
+    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+    hit = _HOST_COPIES.get(key)
+    if hit is None:
+        if len(_HOST_COPIES) > 64:
+            _HOST_COPIES.clear()
+        hit = t.detach().cpu().contiguous().float()
+        _HOST_COPIES[key] = hit
+    return hit
+
+
 @_device_op
 def ray_sampler(reflect, pivots, tbn, view_tangent, alpha):
     """network.RaySampler.forward.  tbn [...,3,3], view_tangent [...,3], alpha [...,1] -> dirs [...,3,R], uv [...,2,R],
@@ -529,7 +547,7 @@ def ray_sampler(reflect, pivots, tbn, view_tangent, alpha):
     tb = _chk(tbn.reshape(npix, 3, 3).contiguous(), 'tbn')
     al = _chk(alpha.reshape(npix).contiguous(), 'alpha')
     vt = _chk(view_tangent.reshape(npix, 3).contiguous(), 'view_tangent') if reflect else None
-    piv = pivots.detach().cpu().contiguous().float()
+    piv = _host_copy(pivots)
     dirs = torch.empty(lead + (3, R), dtype=torch.float32, device=dev)
     uv = torch.empty(lead + (2, R), dtype=torch.float32, device=dev)
     dt = torch.empty(lead + (3, R), dtype=torch.float32, device=dev) if reflect else None
