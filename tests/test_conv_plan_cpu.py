@@ -52,7 +52,7 @@ def test_packed_weight_sizes(kind, h, cins, c_out):
     wstride = (cpad + 127) // 128 * 128
     assert f32 == (9 if kind == 0 else 16) * ctot * wstride
     if kind == 0 and cpad == 80:
-        extra = (ctot // 4 + 2) * 5120
+        extra = (ctot // 4 + 3) * 5120          # + the look-ahead padding: three K steps since r05 (W80_BDIST_K)
     elif kind == 0:
         extra = 0 if cpad % 64 else (cpad // 64) * (ctot // 2 + 5) * 2048
     elif kind == 2:     # r05: the pair layout of conv_wino2p_kernel — K steps in pairs of 2 x 4608 floats, one pair of look-ahead padding
