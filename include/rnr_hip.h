@@ -367,8 +367,8 @@ int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
  * buffer per convolution in flight (calls on the same stream may share one).  After a failed launch: zero it again.
  * Run-to-run reproducibility: the statistics are double-precision atomics whose order varies between runs.  What a workgroup
  * adds is a sum of six to twelve float32 lane sums (<= 28 significant bits), so the double additions are EXACT — hence
- * order-independent — as long as the partial sums of a channel and view span less than ~2^20 in magnitude (53 - 28 - log2(number
- * of workgroups) bits of headroom); that is the case for activations of any trained network and is why 16 000 frame groups have
+ * order-independent — as long as the non-zero partial sums of a channel and view span less than ~2^17 in magnitude (53 - 28 - log2(number
+ * of workgroups) bits of headroom for 512 workgroups per view); that is the case for activations of any trained network and is why 16 000 frame groups have
  * come out bit-identical run after run (scripts/t_fused_stress.py), but it is a property of the data, not of the code: with a wider
  * spread scale / shift — and everything downstream — may differ in the last bits between runs, exactly like rnr_conv2d +
  * rnr_bn_finalize.  The in-launch split-K combine itself is order-independent by construction.
