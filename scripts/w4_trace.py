@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--views', type=int, default=16)
     ap.add_argument('--layers', default='2,8')
+    ap.add_argument('--fine', action='store_true', help='the W4_TRACE build of conv_wino4_kernel also marks the inside of its prologue')
     a = ap.parse_args()
     L = _lib.load()
     L.rnr_debug_w4_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -59,9 +60,12 @@ def main():
         for i, name in enumerate(PHASES):
             print('   %-24s mean %7.2f us   p10 %7.2f  p90 %7.2f' % (name, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
         print('   %-24s mean %7.2f us' % ('workgroup total', (ts[:, 6] - ts[:, 0]).mean()))
-        fine = (t[:, [0, 8, 9, 10, 11, 1]].astype(np.int64) - base) * 0.01
-        print('   inside "index math": tile_coords %.2f, tile origin + staging item %.2f, weight descriptor etc. %.2f, chunk_src %.2f, load requests %.2f us' %
-              tuple(np.diff(fine, axis=1).mean(0)))
+        if a.fine:
+            fine = (t[:, [0, 8, 9, 10, 11, 1]].astype(np.int64) - base) * 0.01
+            print('   inside "index math": tile_coords %.2f, tile origin + staging item %.2f, weight descriptor etc. %.2f, chunk_src %.2f, load requests %.2f us' %
+                  tuple(np.diff(fine, axis=1).mean(0)))
+            lr = np.diff(fine, axis=1)[:, 4]
+            print('   load requests: first workgroup of a CU (nothing before it) %.2f us, later ones %.2f us' % (lr[wg < 256].mean(), lr[wg >= 256].mean()))
         gaps, periods = [], []
         for c in np.unique(cuid):
             w = np.where(cuid == c)[0]
@@ -69,8 +73,6 @@ def main():
             gaps += list(ts[w[1:], 0] - ts[w[:-1], 6])
             periods += list(ts[w[1:], 0] - ts[w[:-1], 0])
         gaps, periods = np.array(gaps), np.array(periods)
-        lr = np.diff(fine, axis=1)[:, 4]
-        print('   load requests: first workgroup of a CU (nothing before it) %.2f us, later ones %.2f us' % (lr[wg < 256].mean(), lr[wg >= 256].mean()))
         print('   tile period on a CU      mean %7.2f us   idle gap between workgroups of a CU: mean %.2f us (p10 %.2f, p90 %.2f)' % (
             periods.mean(), gaps.mean(), np.percentile(gaps, 10), np.percentile(gaps, 90)))
         # synchronisation: start phase of every workgroup modulo the tile period, circular spread (1 = all CUs in lockstep, 0 = uniform)
