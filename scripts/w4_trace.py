@@ -1,8 +1,12 @@
-"""Per-workgroup timeline of conv_wino4_kernel (diagnostic build only: scripts/mkvariant.sh trace "-DW4_TRACE", then
-RNR_HIP_LIB=$PWD/build_abl/librnr_trace.so python scripts/w4_trace.py --layers 2,8 --views 16).
-Wave 0 of every workgroup writes 100 MHz wall-clock marks: 0 start, 1 first weight / halo loads requested, 2 ... landed, 3 first image
-staged (barrier), 4 K loop done, 5 plane rows exchanged, 6 statistics added and stores issued.  Prints the mean length of each phase, how far apart the workgroups of
-one CU start (tile period), the idle gap between two workgroups of a CU, and how synchronised the CUs are."""
+"""Per-workgroup timeline of a convolution kernel from a diagnostic build that writes wall-clock marks (100 MHz) in wave 0 of every workgroup:
+  conv_wino4_kernel      scripts/experiments/conv_wino4_trace_fastdiv_r05.diff, scripts/mkvariant.sh trace "-DW4_TRACE"     --layers 1,2,8  [--fine]
+  conv_wino2p_kernel<2>  scripts/experiments/conv_wino2p_trace_r05.diff,        scripts/mkvariant.sh trace2p "-DW2P_TRACE"  --layers 14,16,18,20
+  conv_wino80_kernel     the same five marks in conv_wino80.inc (-DW80_TRACE)                                                --layers 22
+then  RNR_HIP_LIB=$PWD/build_abl/librnr_trace.so python scripts/w4_trace.py --layers 2,8 --views 16.
+Marks: 0 start, 1 first weight / halo loads requested, 2 ... landed, 3 first image staged (barrier), 4 K loop done, 5 plane rows
+exchanged, 6 statistics added and stores issued (kernels without marks 1 / 2 write 1 = 2 = 3).  Prints the mean length of each phase, how
+far apart the workgroups of one CU start, the idle gap between two workgroups of a CU (meaningful with one workgroup per CU) and how
+synchronised the CUs are.  Output of r05: profiles/r05_wino4_tile_timeline.txt."""
 import argparse
 import ctypes
 import os
