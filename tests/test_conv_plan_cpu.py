@@ -111,7 +111,7 @@ def test_winograd_f4x4_plan_and_image_size():
         ctot = sum(pad16(c) for c in cins)
         w2 = L.rnr_packed_weight_floats(ctypes.byref(desc(0, cins, c_out, _lib.CONV_WINOGRAD)))
         w4 = L.rnr_packed_weight_floats(ctypes.byref(desc(0, cins, c_out, both)))
-        assert w4 == w2 + (pad16(c_out) // 64) * (ctot // 2 + 1) * 4608
+        assert w4 == w2 + (pad16(c_out) // 64) * (ctot // 2 + 2) * 4608       # + the look-ahead padding: two K steps since r05 (W4_BDIST_K)
     for kind, cins, c_out in ((0, (64, 64), 78), (1, (64,), 128), (2, (128, 128), 64)):
         assert (L.rnr_packed_weight_floats(ctypes.byref(desc(kind, cins, c_out, both))) ==
                 L.rnr_packed_weight_floats(ctypes.byref(desc(kind, cins, c_out, _lib.CONV_WINOGRAD))))
