@@ -1932,7 +1932,8 @@ static int make_plan(const rnr_conv_desc* d, int N, int H, int W, ConvPlan* p) {
     // gives every CU a workgroup (no split-K form)
     static const int min_wgs4 = [] { const char* e = getenv("RNR_WINO4_MIN_WGS"); return e ? atoi(e) : RNR_WINO4_MIN_WGS; }();
     if ((d->flags & RNR_CONV_WINOGRAD) && (d->flags & RNR_CONV_WINOGRAD4) && d->kind == RNR_CONV3x3_REFLECT && H % W4_PH == 0 &&
-        W % W4_PW == 0 && d->c_out_pad % W4_BN == 0 && view_elems < (1L << 30)) {
+        W % W4_PW == 0 && d->c_out_pad % W4_BN == 0 && view_elems < (1L << 30) &&
+        (!W4_BN_LDS || d->c_in0_pad + d->c_in1_pad <= W4_BN_MAXC)) {      // the kernel's LDS table of BatchNorm scale / shift holds that many channels
         const long wgs = (long)N * (H / W4_PH) * (W / W4_PW) * (d->c_out_pad / W4_BN);
         // small grids are cut over K like the F(2x2, .) ones — slices of >= RNR_WINO4_SPLIT_MIN_CHUNKS chunks, at most 8, and the
         // split grid must give every CU its workgroup again (this kernel runs one workgroup per CU)

@@ -122,6 +122,9 @@ def test_winograd_f4x4_plan_and_image_size():
     assert L.rnr_conv_algorithm(ctypes.byref(d), 8, 256, 240) == 1           # width not a multiple of 32
     assert L.rnr_conv_algorithm(ctypes.byref(desc(0, (128,), 128, _lib.CONV_WINOGRAD)), 8, 256, 256) == 1
     assert L.rnr_conv_workspace_bytes(ctypes.byref(d), 8, 256, 256) == 256   # never split over K
+    # the kernel keeps BatchNorm scale / shift of every input channel in a 1024-entry LDS table (r05): more channels -> F(2x2, 3x3)
+    assert L.rnr_conv_algorithm(ctypes.byref(desc(0, (512, 512), 128, both)), 8, 256, 256) == 4
+    assert L.rnr_conv_algorithm(ctypes.byref(desc(0, (1024, 512), 128, both)), 8, 256, 256) == 1
 
 
 def test_winograd_f4x4_split_grids():
