@@ -495,6 +495,13 @@ int rnr_view_dir_map(const float* proj_inv, const float* R_inv, float* out_world
 int rnr_tbn_map(const float* normal_map, const int32_t* face_index_map, const float* face_tangents,
                 int num_faces, float* out, int num_views, int height, int width, void* stream);
 
+/* The per-pixel 3x3 products of the reference's view loop, test_rnr.py:314:
+ *   torch.matmul(TBN_map.reshape((-1, 3, 3)).transpose(-2, -1), view_dir_map.reshape((-1, 3, 1)))
+ * tbn [P,3,3] (row-major records, as rnr_tbn_map writes them), vec [P,3], out [P,3];  out[p] = tbn[p]^T vec[p] when transposed != 0,
+ * tbn[p] vec[p] otherwise.  ((c z + (b y + a x)) with fused multiply-adds: <= 1 ulp per term from the batched-GEMM result.)
+ * The drop-in render.get_TBN_map returns a tensor that answers exactly this torch.matmul call with this entry point. */
+int rnr_tbn_matvec(const float* tbn, const float* vec, float* out, long num_pixels, int transposed, void* stream);
+
 /* network.RaySampler.forward (network.py:445-472).  reflect != 0: mode 'reflect' (needs view_tangent), else the
  * pivots themselves.  pivots_host [3,R] (HOST).  tbn [P,3,3], view_tangent [P,3], alpha [P];
  * rays_dir [P,3,R], rays_uv [P,2,R], rays_dir_tangent [P,3,R] (reflect mode only; may be NULL). */

@@ -1472,6 +1472,32 @@ extern "C" int rnr_tbn_map(const float* normal_map, const int32_t* face_index_ma
     return check_launch("tbn_map_kernel");
 }
 
+// out[p][i] = sum_j M[p][i][j] v[p][j] with M = tbn[p] (transposed = 0) or tbn[p]^T (transposed = 1): the per-pixel 3x3 products of
+// test_rnr.py:314 (torch.matmul(TBN_map.reshape((-1, 3, 3)).transpose(-2, -1), view_dir_map.reshape((-1, 3, 1)))), which torch hands to
+// rocBLAS as 262 144 batched 3 x 3 GEMMs (1.9 ms per 512^2 view; this launch: a few us).  One pixel per thread; the 36 + 12 bytes of
+// a pixel are read with 4-byte loads that the L1 merges (consecutive threads, consecutive records).
+__global__ void __launch_bounds__(256)
+tbn_matvec_kernel(const float* __restrict__ tbn, const float* __restrict__ v, float* __restrict__ out, long npix, int transposed) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const float* m = tbn + p * 9;
+    const float x = v[p * 3 + 0], y = v[p * 3 + 1], z = v[p * 3 + 2];
+    float o[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float a = transposed ? m[i] : m[3 * i], b = transposed ? m[3 + i] : m[3 * i + 1], c = transposed ? m[6 + i] : m[3 * i + 2];
+        o[i] = __builtin_fmaf(c, z, __builtin_fmaf(b, y, a * x));
+    }
+    out[p * 3 + 0] = o[0]; out[p * 3 + 1] = o[1]; out[p * 3 + 2] = o[2];
+}
+
+extern "C" int rnr_tbn_matvec(const float* tbn, const float* vec, float* out, long num_pixels, int transposed, void* stream) {
+    RNR_REQUIRE(tbn && vec && out && num_pixels > 0, "rnr_tbn_matvec: bad arguments");
+    hipLaunchKernelGGL(tbn_matvec_kernel, dim3((unsigned)((num_pixels + 255) / 256)), dim3(256), 0, as_stream(stream), tbn, vec, out,
+                       num_pixels, transposed);
+    return check_launch("tbn_matvec_kernel");
+}
+
 extern "C" int rnr_ray_sampler(int reflect, const float* pivots_host, int num_rays, const float* tbn,
                                const float* view_tangent, const float* alpha, float* rays_dir, float* rays_uv,
                                float* rays_dir_tangent, long num_pixels, void* stream) {

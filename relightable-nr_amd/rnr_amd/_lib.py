@@ -118,6 +118,7 @@ SIGNATURES = {
     'rnr_obj_parse': (c_int, [ctypes.c_char_p, c_size_t, P(RnrObjCounts)] + [c_void_p] * 6),
     'rnr_view_dir_map': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rnr_tbn_map': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rnr_tbn_matvec': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),
     'rnr_ray_sampler': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 ctypes.c_long, c_void_p]),
     'rnr_texture_mapper': (c_int, [c_void_p, c_void_p, P(c_void_p), P(c_int), c_int, c_int, c_int, c_void_p, c_int,

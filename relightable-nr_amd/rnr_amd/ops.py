@@ -515,6 +515,18 @@ def tbn_map(normal_map, face_index_map, tangents):
     return out
 
 
+@_device_op
+def tbn_matvec(tbn, vec, transposed=True):
+    """out[p] = tbn[p]^T vec[p] (transposed) or tbn[p] vec[p]: tbn [P,3,3] contiguous, vec [P,3] contiguous -> [P,3]
+    (test_rnr.py:314's batched product in one launch)."""
+    L = _lib.load()
+    _chk(tbn, 'tbn'); _chk(vec, 'vec')
+    P = tbn.shape[0]
+    out = torch.empty(P, 3, dtype=torch.float32, device=tbn.device)
+    check(L.rnr_tbn_matvec(_ptr(tbn), _ptr(vec), _ptr(out), P, 1 if transposed else 0, _stream()))
+    return out
+
+
 _HOST_COPIES = {}
 
 

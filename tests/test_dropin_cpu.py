@@ -224,3 +224,19 @@ def test_camera_modes_match_reference(golden):
         nr.Renderer(camera_mode='orbit')
     r = nr.Renderer(camera_mode='look_at', viewing_angle=30)
     assert abs(r.eye[2] + (1.0 / np.tan(np.radians(30)) + 1)) < 1e-12
+
+
+def test_tbn_map_type_is_a_plain_tensor_off_the_gpu():
+    """render.TBNMap (what get_TBN_map returns) overrides one device-side matmul form; on the CPU, and for every other operation,
+    it is torch's own tensor: same values, plain result types, views keep the type."""
+    import render
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(2, 4, 4, 3, 3, generator=g).as_subclass(render.TBNMap)
+    v = torch.randn(2, 4, 4, 3, generator=g)
+    got = torch.matmul(t.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))
+    want = torch.matmul(t.as_subclass(torch.Tensor).reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))
+    assert type(got) is torch.Tensor and torch.equal(got, want)
+    assert type(t.reshape(-1, 3, 3)) is render.TBNMap and type(t.reshape(-1, 3, 3).transpose(-2, -1)) is render.TBNMap
+    assert type(t[0]) is render.TBNMap
+    assert type(t + 1) is torch.Tensor and type(t.sum()) is torch.Tensor and type(torch.cat([t, t])) is torch.Tensor
+    assert not bool(torch.isnan(t).sum() > 0)

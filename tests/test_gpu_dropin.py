@@ -453,3 +453,37 @@ def ops_project(ras, proj, pose):
     return ops.project_vertices(ras.vertices[0].contiguous(), proj, pose[:, :3, :3].contiguous(), pose[:, :3, 3].contiguous(),
                                 ras.img_size)
 
+
+
+def test_tbn_map_matmul_is_one_launch_and_equals_torch():
+    """test_rnr.py:314's batched product on a get_TBN_map result goes through rnr_tbn_matvec and equals torch's batched GEMM; other
+    forms of the product, and every other operation, stay torch's."""
+    import render
+    g = torch.Generator().manual_seed(11)
+    tbn_plain = torch.randn(2, 96, 80, 3, 3, generator=g).to(DEV)
+    v = torch.randn(2, 96, 80, 3, generator=g).to(DEV)
+    tbn = tbn_plain.as_subclass(render.TBNMap)
+    calls = []
+    from rnr_amd import ops
+    orig = ops.tbn_matvec
+    ops.tbn_matvec = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        got = torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))           # the script's line
+        got_plain_order = torch.matmul(tbn.reshape((-1, 3, 3)), v.reshape((-1, 3, 1)))
+        assert len(calls) == 2
+        other = torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), torch.cat([v, v], -1).reshape((-1, 3, 2)))     # not the form: torch's
+        assert len(calls) == 2
+    finally:
+        ops.tbn_matvec = orig
+    want = torch.matmul(tbn_plain.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))
+    want_plain_order = torch.matmul(tbn_plain.reshape((-1, 3, 3)), v.reshape((-1, 3, 1)))
+    want_other = torch.matmul(tbn_plain.reshape((-1, 3, 3)).transpose(-2, -1), torch.cat([v, v], -1).reshape((-1, 3, 2)))
+    assert type(got) is torch.Tensor and got.shape == want.shape
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 4e-7 * scale          # three fused multiply-adds against the GEMM's rounding
+    assert (got_plain_order - want_plain_order).abs().max().item() <= 4e-7 * scale
+    assert torch.equal(other, want_other) and type(other) is torch.Tensor
+    # the rest of the script's expression, and what the ray samplers get
+    vt = got[..., 0].reshape(v.shape)
+    assert vt.shape == v.shape and type(torch.nn.functional.normalize(vt, dim=-1)) is torch.Tensor
+    assert type(tbn.reshape((-1, 3, 3))) is render.TBNMap and tbn.data_ptr() == tbn_plain.data_ptr()
