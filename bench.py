@@ -494,7 +494,8 @@ def dropin_view_loop_block(sc, args, dev):
                 'out, then .astype(float32) and torch.from_numpy(...).to(device) in test_rnr.py:324-328): two host round trips and a '
                 'stream drain per view that no drop-in can remove; sh_basis_on_device is the same loop with '
                 'evaluate_sh_basis(..., as_tensor=True).  stage_ms are HIP-event intervals between the reference\'s own call boundaries '
-                '(host-side waits of a stage appear in it as idle GPU time).  Not the headline value.',
+                '(host-side waits of a stage appear in it as idle GPU time).  The script\'s batched torch.matmul of test_rnr.py:314 is '
+                'answered by rnr_tbn_matvec (render.get_TBN_map returns a render.TBNMap; INTEGRATION.md Level 1).  Not the headline value.',
     }
 
 

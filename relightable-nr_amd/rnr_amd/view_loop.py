@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-STAGES = ('rasterizer', 'get_TBN_map', 'get_view_dir_map', 'view_dir_tangent(torch)', 'evaluate_sh_basis(+host)', 'texture_mapper',
+STAGES = ('rasterizer', 'get_TBN_map', 'get_view_dir_map', 'view_dir_tangent(torch.matmul -> rnr_tbn_matvec; normalize)', 'evaluate_sh_basis(+host)', 'texture_mapper',
           'ray_sampler x2', 'cat(torch)', 'render_net', 'post_scale(torch)', 'ray_renderer')
 
 
@@ -106,7 +106,7 @@ class DropinViewLoop:
             view_dir_map_tangent = torch.matmul(TBN_map.reshape((-1, 3, 3)).transpose(-2, -1),
                                                 view_dir_map.reshape((-1, 3, 1)))[..., 0].reshape(view_dir_map.shape)
             view_dir_map_tangent = torch.nn.functional.normalize(view_dir_map_tangent, dim=-1)
-            mark('view_dir_tangent(torch)')
+            mark('view_dir_tangent(torch.matmul -> rnr_tbn_matvec; normalize)')
             # SH basis value for view_dir_map (test_rnr.py:320-329, the force_recompute branch)
             if self.sh_on_device:
                 sh_basis_map = sph_harm.evaluate_sh_basis(lmax=2, directions=view_dir_map.reshape((-1, 3)), as_tensor=True) \
