@@ -43,6 +43,12 @@ def parse(argv=None):
     ap.add_argument('--views-per-step', type=int, default=16,
                     help='camera poses per GPU per step (r04: 16; 8 until then — 2, 4, 8, 16, 32 views per step measure 483, 527, 547, 557, 561 frames/s)')
     ap.add_argument('--img-size', type=int, default=512)
+    ap.add_argument('--windows', type=int, default=3,
+                    help='timed windows of exactly --steps steps each (barrier + synchronize around every one); `value` is the '
+                         'median window, all of them are printed')
+    ap.add_argument('--prewarm-seconds', type=float, default=2.0,
+                    help='untimed steps rendered for this long in front of the --warmup steps (a fresh box starts cold: clocks, '
+                         'allocator, code objects); 0 = none')
     ap.add_argument('--nf0', type=int, default=64)
     ap.add_argument('--tex-ch', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -323,6 +329,35 @@ def algo_block(unet, n_views, stage_ms, peak, masked_out_layer, direct_tf=None, 
     return blk
 
 
+def step_series_block(series, dt, K):
+    """Per-step attribution of the timed window (rank 0's events): where a step's wall time went, and which steps stand out.
+      step_ms                  HIP-event interval start -> end of each step on the launch stream
+      gap_ms                   end of step k -> start of step k + 1 on the GPU (idle unless the host is behind)
+      unet_ms                  the U-Net stage inside each step (HIP events)
+      non_unet_ms_per_step     mean(step_ms - unet_ms): rasterizer + shading inputs + ray renderer + whatever idle time
+                               the stream saw inside the step
+      gpu_idle_ms_per_step     (window wall time - sum(step_ms)) / K + mean over steps of (step_ms - min(step_ms)): wall time not
+                               covered by a step's events plus what the steps took beyond the fastest one (same kernels, same
+                               sizes: the excess is idle stream time or a clock dip)
+      slow_steps               steps > 1.3 x the median step_ms, by index"""
+    out = {'host_enqueue_ms': [round(x, 3) for x in series.get('host_enqueue_ms', [])]}
+    if 'step_ms' not in series:
+        return {'step_series': out}
+    st, un = series['step_ms'], series['unet_ms']
+    med = float(np.median(st))
+    out.update({
+        'step_ms': [round(x, 3) for x in st], 'gap_ms': [round(x, 3) for x in series['gap_ms']],
+        'unet_ms': [round(x, 3) for x in un],
+        'ms_per_step_median': med, 'ms_per_step_min': float(np.min(st)), 'ms_per_step_max': float(np.max(st)),
+        'non_unet_ms_per_step': float(np.mean(np.asarray(st) - np.asarray(un))),
+        'gpu_idle_ms_per_step': float((dt * 1e3 - np.sum(st)) / K + np.mean(np.asarray(st) - np.min(st))),
+        'wall_minus_event_span_ms': dt * 1e3 - series['events_span_ms'],
+        'slow_steps': [{'step': int(i), 'ms': round(float(x), 3), 'unet_ms': round(float(un[i]), 3)}
+                       for i, x in enumerate(st) if x > 1.3 * med],
+    })
+    return {'step_series': out}
+
+
 def make_pipeline(sc, args, dev, V, **kw):
     from rnr_amd.pipeline import RNRPipeline
     opts = dict(nf0=args.nf0, max_views=V, device=dev, sh_coeff=sc['sh_coeff'], sh_lmax=10,
@@ -331,8 +366,9 @@ def make_pipeline(sc, args, dev, V, **kw):
     return RNRPipeline(sc['mesh'], args.img_size, sc['textures'], sc['unet_sd'], sc['pivots_spec'], sc['pivots_diff'], None, **opts)
 
 
-def hook_unet_events(unet, n_events):
-    """HIP events around UNetPlan.forward on the launch stream; returns (events, restore())."""
+def hook_unet_events(unet, n_events, series=False):
+    """HIP events around UNetPlan.forward on the launch stream; returns restore(), which un-hooks and gives the mean
+    interval in ms (series=True: the list of per-call intervals)."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_events)]
     orig = unet.forward
     count = [0]
@@ -350,7 +386,8 @@ def hook_unet_events(unet, n_events):
 
     def restore():
         unet.forward = orig
-        return float(np.mean([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(min(count[0], n_events))]))
+        ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(min(count[0], n_events))]
+        return ms if series else float(np.mean(ms))
     return restore
 
 
@@ -613,40 +650,96 @@ def main(argv=None):
         if use_dist:
             gather.drain()
 
+    # pre-warm (untimed, in FRONT of the W warm-up steps): a fresh box hands over a GPU in its idle power state and a process
+    # whose allocator, code objects and clocks have seen nothing yet; W = 3..5 steps are 0.1 s.  Steps are rendered until
+    # --prewarm-seconds have passed (host clock, synchronised) — the timed region below is untouched: exactly K steps.
+    prewarm_steps = 0
+    if not stub and args.prewarm_seconds > 0:
+        tp = time.perf_counter()
+        while time.perf_counter() - tp < args.prewarm_seconds and prewarm_steps < 200:
+            step(prewarm_steps % max(1, args.warmup + args.steps))
+            prewarm_steps += 1
+            sync()
+        drain()
     for s in range(args.warmup):
         step(s)
     drain()
-    # ---- per-stage HIP-event timing of the dominant stage (U-Net convs) on the launch stream ----
-    restore = None
+    # ---- HIP events on the launch stream: around every step and around the dominant stage (U-Net convs) of every step ----
     active_tiles, out_tiles_per_step, out_step = None, 0, None
+    unet_forward_plain = None
     if not stub:
         out_step = pipe.unet.steps[-1]
         out_tiles_per_step = pipe.unet.L.rnr_conv_tile_count(ctypes.byref(out_step['desc']), V, args.img_size, args.img_size)
         active_tiles = torch.zeros(1, dtype=torch.int64, device=dev)     # out-layer pixel tiles actually computed
-        restore_events = hook_unet_events(pipe.unet, args.steps)
-        hooked = pipe.unet.forward
+        unet_forward_plain = pipe.unet.forward
 
-        def counting_forward(net_in, n_views=None, consumer_alpha=None):
-            r = hooked(net_in, n_views, consumer_alpha)
-            if consumer_alpha is not None and out_tiles_per_step:
-                active_tiles.add_(pipe.unet._tile_mask[:out_tiles_per_step].sum())
-            return r
-        pipe.unet.forward = counting_forward
-        restore = restore_events
-    if use_dist:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
+    def timed_window():
+        """EXACTLY K steps between barrier + synchronize on both sides.  Returns (wall seconds, series) where series holds,
+        per step, the HIP-event interval start -> end of the step on the launch stream (step_ms), the interval from its end
+        to the next step's start (gap_ms: GPU idle between steps, 0 while the host runs ahead), the U-Net stage inside it
+        (unet_ms) and the host time spent enqueueing it (host_enqueue_ms) — test_rnr.py:265, 374 prints the same per-view
+        stamps (t_prep t_raster t_preproc t_sh t_network t_render)."""
+        K = args.steps
+        ev_s = ev_e = None
+        restore_u = None
+        if not stub:
+            ev_s = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+            ev_e = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+            pipe.unet.forward = unet_forward_plain
+            restore_u = hook_unet_events(pipe.unet, K, series=True)
+            hooked = pipe.unet.forward
+
+            def counting_forward(net_in, n_views=None, consumer_alpha=None):
+                r = hooked(net_in, n_views, consumer_alpha)
+                if consumer_alpha is not None and out_tiles_per_step:
+                    active_tiles.add_(pipe.unet._tile_mask[:out_tiles_per_step].sum())
+                return r
+            pipe.unet.forward = counting_forward
+        host_ms = []
+        if use_dist:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        img_ = None
+        for k, s in enumerate(range(args.warmup, args.warmup + K)):
+            th = time.perf_counter()
+            if ev_s is not None:
+                ev_s[k].record()
+            img_ = step(s)
+            if ev_e is not None:
+                ev_e[k].record()
+            host_ms.append((time.perf_counter() - th) * 1e3)
+        drain()
+        sync()
+        if use_dist:
+            dist.barrier()
+        sync()
+        dt_ = time.perf_counter() - t0
+        ser = {'host_enqueue_ms': host_ms}
+        if ev_s is not None:
+            ser['step_ms'] = [ev_s[k].elapsed_time(ev_e[k]) for k in range(K)]
+            ser['gap_ms'] = [ev_e[k].elapsed_time(ev_s[k + 1]) for k in range(K - 1)]
+            ser['unet_ms'] = restore_u()
+            pipe.unet.forward = unet_forward_plain
+            ser['events_span_ms'] = ev_s[0].elapsed_time(ev_e[K - 1])
+        return dt_, ser, img_
+
+    n_windows = 1 if stub else max(1, args.windows)
+    windows = []
     img = None
-    for s in range(args.warmup, args.warmup + args.steps):
-        img = step(s)
-    drain()
-    sync()
-    if use_dist:
-        dist.barrier()
-    sync()
-    dt = time.perf_counter() - t0
-    unet_ms = restore() if restore else dt / args.steps * 1e3
+    for w in range(n_windows):
+        dt_w, ser_w, img = timed_window()
+        if use_dist:
+            tmax = torch.tensor([dt_w], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_w = float(tmax.item())
+        windows.append((dt_w, ser_w))
+    # value policy: the MEDIAN window (by max-over-ranks wall time) of n_windows windows of exactly K steps each; every
+    # window's rate is printed (`windows`), the series below belong to the window `value` is taken from
+    order = sorted(range(n_windows), key=lambda i: windows[i][0])
+    w_sel = order[(n_windows - 1) // 2]
+    dt, series = windows[w_sel]
+    unet_ms = float(np.mean(series['unet_ms'])) if 'unet_ms' in series else dt / args.steps * 1e3
     gather_check = None
     if args.check_gather and use_dist:
         got = gather.latest[rank * V:(rank + 1) * V]
@@ -684,10 +777,6 @@ def main(argv=None):
         dist.all_reduce(t8max, op=dist.ReduceOp.MAX)
         dt8 = float(t8max.item())
         del gather8
-    if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     # ranks that actually took part: every rank adds 1 through the process group (not dist.get_world_size(), which only
     # repeats the environment); a mismatch with --gpus is a failed run, not a number
     n_ranks_seen = 1
@@ -703,7 +792,7 @@ def main(argv=None):
         d_out, (oh, ow) = out_step['desc'], out_step['in_hw']
         out_flops_view = 2 * oh * ow * 9 * (d_out.c_in0 + d_out.c_in1) * d_out.c_out
         if args.tile_skip and out_tiles_per_step:
-            skipped = 1.0 - float(active_tiles.item()) / (out_tiles_per_step * args.steps)
+            skipped = 1.0 - float(active_tiles.item()) / (out_tiles_per_step * args.steps * n_windows)
         flops_view = pipe.unet.flops_per_view
         flops_step = (flops_view - skipped * out_flops_view) * V
         n_conv = len(pipe.unet.steps)
@@ -728,6 +817,13 @@ def main(argv=None):
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'n_ranks_seen': n_ranks_seen, 'rccl_version': rccl,
+            'value_policy': 'median of %d timed windows of exactly %d steps each (barrier + synchronize around every window, MAX over '
+                            'ranks per window); `windows` lists every window, the per-step series are those of the median window'
+                            % (n_windows, args.steps),
+            'windows': [{'frames_per_s': args.steps * world * V / w[0], 'ms_per_step': w[0] / args.steps * 1e3,
+                         'is_value': i == w_sel} for i, w in enumerate(windows)],
+            'prewarm_steps': prewarm_steps,
+            **step_series_block(series, dt, args.steps),
             'config': {'workload': workload_name(args, world, V, sc),
                        'views_per_step_per_gpu': V, 'global_views_per_step': world * V,
                        'parallelism': 'views sharded x%d, all_gather of frames' % world,
