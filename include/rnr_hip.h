@@ -373,6 +373,9 @@ int rnr_conv2d_masked(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
  * spread scale / shift — and everything downstream — may differ in the last bits between runs, exactly like rnr_conv2d +
  * rnr_bn_finalize.  The in-launch split-K combine itself is order-independent by construction.
  */
+/* ZERO-INITIALISE this struct (`rnr_conv_bn bn = {0};` / memset) before filling it: it has grown (running_mean, running_var,
+ * momentum were added in r05) and carries no size field — a caller compiled against the five-field form that leaves the tail
+ * uninitialised hands garbage running_* pointers to rnr_conv2d_fused, i.e. a wild device write when num_views == 1. */
 typedef struct rnr_conv_bn {
     const float* gamma; /* [c_out] BatchNorm weight; NULL = no BatchNorm behind this convolution */
     const float* beta;  /* [c_out] */

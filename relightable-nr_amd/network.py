@@ -66,10 +66,18 @@ class TextureMapper(nn.Module):
         reference's `if self.apply_sh` (network.py:84) drains the stream once per view.  Cached per (storage, version): an in-place
         change or a load_state_dict is seen."""
         t = self.apply_sh
-        key = (t.data_ptr(), t._version)
+        key = (id(t), t.data_ptr(), t._version)
         if getattr(self, '_apply_sh_key', None) != key:
             self._apply_sh_key, self._apply_sh_val = key, bool(t)
         return self._apply_sh_val
+
+    def _apply(self, fn, *a, **k):
+        self._apply_sh_key = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._apply_sh_key = None
+        return super()._load_from_state_dict(*a, **k)
 
     def flatten_mipmap(self, start_ch, end_ch):
         """network.py:93-99 (init-time / visualisation helper)."""
@@ -118,13 +126,21 @@ class Rasterizer(nn.Module):
         self._static = {}
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        self._mesh = {}
+        self._static = {}
+        return super()._load_from_state_dict(*a, **k)
+
     def _static_outputs(self, fill_back, device):
         """The entries of the 14-tuple that do not depend on the camera (faces_v_idx, faces_v, faces_vt: gathers of the mesh
         buffers the reference redoes per call, network.py:183-198) and mesh_span on the device (a per-call `.to(device)` of a
-        CPU scalar is a pageable copy that drains the stream): computed once per (fill_back, device), reset by .to() / .cuda()."""
-        # in-place edits of the mesh buffers bump their version counters: a stale gather is never returned
+        CPU scalar is a pageable copy that drains the stream): computed once per (fill_back, device), reset by .to() / .cuda() /
+        load_state_dict.  The returned tensors are SHARED between calls and must be treated as read-only (the reference returns
+        fresh gathers; a caller that edits them in place must clone first)."""
+        # in-place edits of the mesh buffers (and of mesh_span) bump their version counters: a stale gather is never returned
         key = (fill_back, str(device)) + tuple((t.data_ptr(), t._version) for t in
-                                                (self.vertices, self.faces, self.vertices_texcoords, self.faces_vt_idx))
+                                                (self.vertices, self.faces, self.vertices_texcoords, self.faces_vt_idx,
+                                                 self.mesh_span))
         if key not in self._static:
             self._static.clear()
             faces_v_idx = self._both_sides(self.faces) if fill_back else self.faces

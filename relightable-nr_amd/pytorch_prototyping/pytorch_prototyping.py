@@ -163,6 +163,12 @@ class Unet(nn.Module):
         # one plan per (size, device, mode), sized for the largest batch seen; rebuilt when a weight changed in place
         if plan is None or plan.N < n or self._plan_versions.get(key) != ver:
             cin, cout, nf0, nd = self.cfg
+            # the kernels finalise BatchNorm with torch's defaults (eps 1e-5, momentum 0.1: what pytorch_prototyping.py builds);
+            # a module edited to other values would silently diverge from torch, so it is refused
+            for m in self._live_batchnorms():
+                if m.eps != 1e-5 or m.momentum != 0.1:
+                    raise NotImplementedError('Unet: BatchNorm2d(eps=%r, momentum=%r) — the HIP U-Net implements the reference\'s '
+                                              'eps=1e-5, momentum=0.1 only' % (m.eps, m.momentum))
             sd = {'net.' + k: v for k, v in self.state_dict().items()}
             self._plans.pop(key, None)
             plan = UNetPlan(sd, cin, cout, nf0, nd, (h, w), max(n, plan.N if plan is not None else 0), device, bn_mode=mode,

@@ -1,4 +1,7 @@
 """Drop-in `render` (reference: render.py): the functions the inference path uses."""
+import os
+import warnings
+
 import numpy as np
 import torch
 
@@ -41,6 +44,15 @@ class TBNMap(torch.Tensor):
     does not have this exact form — is torch's own and returns plain tensors."""
 
     _VIEW_OPS = None
+    # observability of the fast path: matmuls on a TBNMap answered by rnr_tbn_matvec ('hits') and those that fell through to
+    # torch's batched GEMM ('misses': 1.97 ms per 512 x 512 view through rocBLAS); the first miss warns once per process
+    stats = {'hits': 0, 'misses': 0, 'last_miss': None}
+    _warned = False
+
+    @classmethod
+    def reset_stats(cls):
+        cls.stats.update(hits=0, misses=0, last_miss=None)
+        cls._warned = False
 
     @classmethod
     def _view_ops(cls):
@@ -54,9 +66,20 @@ class TBNMap(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         if func in (torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__) and len(args) == 2 and not kwargs:
-            out = _tbn_matvec(args[0], args[1])
+            with torch._C.DisableTorchFunctionSubclass():         # the checks below must not re-enter this hook per attribute
+                out, why = _tbn_matvec(args[0], args[1])
             if out is not None:
+                cls.stats['hits'] += 1
                 return out
+            if why is not None:
+                cls.stats['misses'] += 1
+                cls.stats['last_miss'] = why
+                if not cls._warned:
+                    cls._warned = True
+                    warnings.warn('render.TBNMap: torch.matmul on a TBN map was NOT answered by rnr_tbn_matvec (%s); torch runs it '
+                                  'as batched 3 x 3 GEMMs (about 2 ms per 512 x 512 view).  test_rnr.py:314 spells it '
+                                  'torch.matmul(TBN_map.reshape((-1, 3, 3)).transpose(-2, -1), view_dir_map.reshape((-1, 3, 1))) '
+                                  'on float32 device tensors; see render.TBNMap.stats' % why, RuntimeWarning, stacklevel=2)
         out = super().__torch_function__(func, types, args, kwargs)
         if func not in cls._view_ops() and isinstance(out, TBNMap):
             out = out.as_subclass(torch.Tensor)
@@ -64,31 +87,42 @@ class TBNMap(torch.Tensor):
 
 
 def _tbn_matvec(a, b):
-    """The overridden product, or None when the operands do not have test_rnr.py:314's form."""
-    if not (isinstance(a, TBNMap) and isinstance(b, torch.Tensor) and a.is_cuda and b.is_cuda and a.device == b.device):
-        return None
-    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != 3 or b.dim() != 3:
-        return None
-    if tuple(a.shape[1:]) != (3, 3) or tuple(b.shape) != (a.shape[0], 3, 1) or a.shape[0] == 0:
-        return None
+    """The overridden product -> (result, None), or (None, reason) when the operands do not have test_rnr.py:314's form
+    (reason None: the override does not apply at all — opted out, or the TBN map is not the left operand)."""
+    if not isinstance(a, TBNMap) or not isinstance(b, torch.Tensor):
+        return None, None
+    if os.environ.get('RNR_TBN_MATMUL', '1') == '0':
+        return None, None
+    if torch.is_autocast_enabled():
+        return None, 'autocast is enabled: left to torch so that the autocast dtype rules apply'
+    if not a.is_cuda:
+        return None, None               # a CPU map: torch's product is the only one there is, nothing is lost
+    if not (b.is_cuda and a.device == b.device):
+        return None, 'operands are not on one GPU'
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        return None, 'dtypes %s x %s, not float32' % (a.dtype, b.dtype)
+    if a.dim() != 3 or b.dim() != 3 or tuple(a.shape[1:]) != (3, 3) or tuple(b.shape) != (a.shape[0], 3, 1) or a.shape[0] == 0:
+        return None, 'shapes %s x %s, not [P,3,3] x [P,3,1]' % (tuple(a.shape), tuple(b.shape))
     if a.requires_grad or b.requires_grad:
-        return None
+        return None, 'an operand requires grad'
     if a.stride() == (9, 1, 3):
         transposed = True
     elif a.stride() == (9, 3, 1):
         transposed = False
     else:
-        return None
+        return None, 'left operand strides %s: neither the [P,3,3] records (9,3,1) nor their transpose (9,1,3)' % (tuple(a.stride()),)
     bt = b.as_subclass(torch.Tensor) if type(b) is not torch.Tensor else b
     if not bt.is_contiguous():
-        return None
+        return None, 'right operand is not contiguous'
     base = a.as_subclass(torch.Tensor).as_strided((a.shape[0], 3, 3), (9, 3, 1))      # the records as rnr_tbn_map wrote them
-    return ops.tbn_matvec(base, bt.reshape(-1, 3), transposed=transposed).reshape(-1, 3, 1)
+    return ops.tbn_matvec(base, bt.reshape(-1, 3), transposed=transposed).reshape(-1, 3, 1), None
 
 
-def get_TBN_map(normal_map, face_index_map, faces_v=None, faces_texcoord=None, tangent=None, check_nan=False):
+def get_TBN_map(normal_map, face_index_map, faces_v=None, faces_texcoord=None, tangent=None, check_nan=False, plain=False):
     """render.py:124-168 -> [N,H,W,3,3].  `check_nan=True` restores the reference's NaN guards (3 host syncs per call,
-    ValueError('nan value detected')); they are off by default to keep the stream asynchronous."""
+    ValueError('nan value detected')); they are off by default to keep the stream asynchronous.  The result is a TBNMap (see
+    there: one matmul form answered by one launch); `plain=True` — or RNR_TBN_MATMUL=0 in the environment — returns /
+    behaves as a plain torch.Tensor for callers that compare bit for bit with torch's batched GEMM, use torch.compile, etc."""
     if tangent is None:
         assert faces_v is not None and faces_texcoord is not None
         tangent = ops.face_tangents(faces_v, faces_texcoord)
@@ -99,7 +133,7 @@ def get_TBN_map(normal_map, face_index_map, faces_v=None, faces_texcoord=None, t
     tbn = ops.tbn_map(normal_map.float().contiguous(), face_index_map.int().contiguous(), tangent)
     if check_nan and torch.isnan(tbn).sum() > 0:
         raise ValueError('nan value detected')
-    return tbn.as_subclass(TBNMap)
+    return tbn if plain else tbn.as_subclass(TBNMap)
 
 
 def _out_of_scope(name):

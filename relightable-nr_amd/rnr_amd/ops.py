@@ -6,6 +6,7 @@ Argument checks mirror the reference extension's CHECK_INPUT (rasterize_cuda.cpp
 contiguous, right dtype, else RuntimeError.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -531,18 +532,21 @@ _HOST_COPIES = {}
 
 
 def _host_copy(t):
-    """float32 CPU copy of a small constant tensor (ray pivots), cached per (storage, version): `.cpu()` on a device buffer is a
-    blocking copy — one stream drain per call in the reference's per-view loop (two per view for the two ray samplers)."""
+    """float32 CPU copy of a small constant tensor (ray pivots): `.cpu()` on a device buffer is a blocking copy — one stream
+    drain per call in the reference's per-view loop (two per view for the two ray samplers).  The copy is cached per tensor
+    OBJECT: the entry holds a weak reference to the tensor and is dropped when the tensor dies, and a hit is only accepted
+    when it is the same live object at the same address, version, shape and dtype (an address recycled by the caching
+    allocator for another tensor, a `.data =` / `set_()` swap or an in-place write all miss)."""
     if not t.is_cuda:
         return t.detach().contiguous().float()
-    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
-    hit = _HOST_COPIES.get(key)
-    if hit is None:
-        if len(_HOST_COPIES) > 64:
-            _HOST_COPIES.clear()
-        hit = t.detach().cpu().contiguous().float()
-        _HOST_COPIES[key] = hit
-    return hit
+    k = id(t)
+    sig = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device.index)
+    hit = _HOST_COPIES.get(k)
+    if hit is not None and hit[0]() is t and hit[1] == sig:
+        return hit[2]
+    host = t.detach().cpu().contiguous().float()
+    _HOST_COPIES[k] = (weakref.ref(t, lambda _r, k=k: _HOST_COPIES.pop(k, None)), sig, host)
+    return host
 
 
 @_device_op

@@ -1,5 +1,7 @@
 """Drop-in `sph_harm` (reference: sph_harm.py) without pyshtools: the basis is evaluated by the HIP kernel
 (real, orthonormal, no Condon-Shortley phase, columns l = 0..lmax, m = -l..l)."""
+import os
+
 import numpy as np
 import torch
 
@@ -18,6 +20,9 @@ def sph2cart(azimuth, elevation, r):
     m = torch if type(azimuth) is torch.Tensor else np
     ce = m.cos(elevation)
     return r * ce * m.cos(azimuth), r * ce * m.sin(azimuth), r * m.sin(elevation)
+
+
+_PINNED_MAX_BYTES = int(float(os.environ.get('RNR_SH_PINNED_MAX_MB', '64')) * (1 << 20))
 
 
 def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None, as_tensor=False):
@@ -41,12 +46,24 @@ def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None, 
     out = ops.sh_basis(d, int(lmax))
     if as_tensor:
         return out
-    host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)     # a block of torch's caching pinned allocator
     # cast on the DEVICE first, then a same-dtype blocking D2H copy: `host.copy_(out)` with float32 -> float64 across devices
     # takes torch's slow conversion path (measured in the drop-in loop at 512^2: 15.6 ms per call against 0.37 ms this way,
     # scripts/exp_dropin_host2.py)
-    host.copy_(out.double())
-    return host.numpy()                                                     # the array keeps the pinned block alive
+    out64 = out.double()
+    nbytes = out64.numel() * 8
+    host = None
+    if nbytes <= _PINNED_MAX_BYTES:
+        try:
+            host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)     # a block of torch's caching pinned allocator
+        except RuntimeError:                                                        # page-locking refused (ulimit -l, fragmentation)
+            host = None
+    if host is None:
+        return out64.cpu().numpy()          # pageable copy: slower, nothing stays page-locked
+    host.copy_(out64)
+    # The array ALIASES the page-locked block and keeps it alive: a caller that stores many results (precompute-style caches of
+    # per-view bases) should store `result.copy()` — torch's caching host allocator recycles the block once the array is gone
+    # but never returns it to the OS.  Results above RNR_SH_PINNED_MAX_MB (default 64) take the pageable path above.
+    return host.numpy()
 
 
 def fit_sh_coeff(samples, sh_basis_val):

@@ -467,14 +467,34 @@ def test_tbn_map_matmul_is_one_launch_and_equals_torch():
     from rnr_amd import ops
     orig = ops.tbn_matvec
     ops.tbn_matvec = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    import warnings
+    render.TBNMap.reset_stats()
     try:
         got = torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))           # the script's line
         got_plain_order = torch.matmul(tbn.reshape((-1, 3, 3)), v.reshape((-1, 3, 1)))
+        assert len(calls) == 2 and render.TBNMap.stats['hits'] == 2 and render.TBNMap.stats['misses'] == 0
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter('always')
+            other = torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), torch.cat([v, v], -1).reshape((-1, 3, 2)))     # not the form: torch's
         assert len(calls) == 2
-        other = torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), torch.cat([v, v], -1).reshape((-1, 3, 2)))     # not the form: torch's
-        assert len(calls) == 2
+        # the miss is visible: counted, explained, and warned about exactly once per process
+        assert render.TBNMap.stats['misses'] == 1 and 'shapes' in render.TBNMap.stats['last_miss']
+        assert sum(issubclass(w.category, RuntimeWarning) and 'rnr_tbn_matvec' in str(w.message) for w in wl) == 1
+        with warnings.catch_warnings(record=True) as wl2:
+            warnings.simplefilter('always')
+            torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), torch.cat([v, v], -1).reshape((-1, 3, 2)))
+        assert render.TBNMap.stats['misses'] == 2 and not wl2
+        # opt-outs: the environment switch and get_TBN_map(..., plain=True) leave the product to torch
+        os.environ['RNR_TBN_MATMUL'] = '0'
+        try:
+            off = torch.matmul(tbn.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))
+        finally:
+            del os.environ['RNR_TBN_MATMUL']
+        assert len(calls) == 2 and render.TBNMap.stats['misses'] == 2
     finally:
         ops.tbn_matvec = orig
+        render.TBNMap.reset_stats()
+    assert torch.equal(off, torch.matmul(tbn_plain.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1))))
     want = torch.matmul(tbn_plain.reshape((-1, 3, 3)).transpose(-2, -1), v.reshape((-1, 3, 1)))
     want_plain_order = torch.matmul(tbn_plain.reshape((-1, 3, 3)), v.reshape((-1, 3, 1)))
     want_other = torch.matmul(tbn_plain.reshape((-1, 3, 3)).transpose(-2, -1), torch.cat([v, v], -1).reshape((-1, 3, 2)))
