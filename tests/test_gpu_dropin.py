@@ -507,3 +507,37 @@ def test_tbn_map_matmul_is_one_launch_and_equals_torch():
     vt = got[..., 0].reshape(v.shape)
     assert vt.shape == v.shape and type(torch.nn.functional.normalize(vt, dim=-1)) is torch.Tensor
     assert type(tbn.reshape((-1, 3, 3))) is render.TBNMap and tbn.data_ptr() == tbn_plain.data_ptr()
+
+
+def test_ray_sampler_pivot_cache_follows_the_tensor_not_the_address():
+    """ops._host_copy (the cached host copy of the pivots buffer, no stream drain per call) is tied to the tensor OBJECT: a
+    second sampler whose pivots land at the recycled address of a dropped one, a `.data =` swap and an in-place edit all get
+    their own pivots (the address / version key alone returned the dead sampler's directions)."""
+    import network
+    from rnr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    tbn = torch.nn.functional.normalize(torch.randn(1, 8, 8, 3, 3, generator=g), dim=-2).to(DEV)
+    vt = torch.nn.functional.normalize(torch.randn(1, 8, 8, 3, generator=g), dim=-1).to(DEV)
+    alpha = torch.ones(1, 8, 8, 1, device=DEV)
+
+    def direct(pivots_cpu):         # CPU pivots take the uncached path
+        return ops.ray_sampler(False, pivots_cpu, tbn, vt, alpha)[0]
+
+    for step_a, step_b in ((5, 10), (10, 5)):
+        a = network.RaySampler(6, 2, step_a, mode='diffuse').to(DEV)
+        want_a = direct(a.pivots_dir.cpu())
+        assert torch.equal(a(tbn, vt, alpha)[0], want_a)
+        ptr = a.pivots_dir.data_ptr()
+        del a
+        b = network.RaySampler(6, 2, step_b, mode='diffuse').to(DEV)     # the caching allocator hands the block out again
+        want_b = direct(b.pivots_dir.cpu())
+        assert not torch.equal(want_a, want_b)
+        got_b = b(tbn, vt, alpha)[0]
+        assert torch.equal(got_b, want_b), 'stale pivots (same address: %s)' % (b.pivots_dir.data_ptr() == ptr)
+        # .data swap and in-place edit on a live module
+        other = network.RaySampler(6, 2, step_a, mode='diffuse').pivots_dir.to(DEV)
+        b.pivots_dir.data = other
+        assert torch.equal(b(tbn, vt, alpha)[0], direct(other.cpu()))
+        b.pivots_dir.mul_(-1.0)
+        assert torch.equal(b(tbn, vt, alpha)[0], direct(b.pivots_dir.cpu()))
+    assert len(ops._HOST_COPIES) <= 4
