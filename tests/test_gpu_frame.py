@@ -1,5 +1,7 @@
 """-m gpu: the whole per-view hot path (poses -> frames) vs the reference golden frame and the oracle.
 Tolerance stated by north_star: PSNR vs reference >= 50 dB; the fp32 MFMA path is held to >= 60 dB here."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -354,6 +356,65 @@ def test_frame1024_c16_vs_oracle(nf0, precision):
     assert (pipe.last['gb']['face_index_map'].cpu() != ref['face_index_map']).float().mean() < 1e-3
     p = orc.psnr(img, ref['image'])
     assert p > 55.0, p
+
+
+def test_config5_as_written_1024_c16_65536_faces_probe_1600x3200():
+    """BASELINE configs[4] / SURVEY 8(d) config 5 at its own sizes on one GPU: 1024 x 1024, the 65 536-face
+    sphere, 16-channel neural texture (texture side 512; U-Net input 78 + 6 + 16 = 100 -> 78, nf0 = 64), lighting from the
+    1600 x 3200 synthetic environment map (sum of 8 Gaussians, seed 2) through network.LightingLP (network.py:631-699: area resize
+    to 1600 x 3200 — the identity at this size —, 4096 bilinear samples, SH fit with lmax 10).  Checked:
+      * SH coefficients <= 2e-5 of the oracle's fit of the same probe;
+      * face_index_map / alpha EQUAL to the oracle rasterizer on the same projected vertices (1 048 576 pixels x 65 536 faces);
+      * the frame of the product plan (Winograd kernels) <= 1e-5 of the all-direct-convolution plan's;
+      * the frame vs the CPU oracle's full 1024^2 frame: PSNR >= 60 dB."""
+    import network
+    from oracle import rnr_oracle as orc
+    from rnr_amd import scene, testing
+    from rnr_amd.pipeline import RNRPipeline
+    S, C = 1024, 16
+    ps, pd = testing.ray_pivots(6, 2, 5), testing.ray_pivots(6, 2, 10)
+    mesh = scene.uv_sphere(128, 256)
+    assert len(mesh['f_v_idx']) == 65536
+    textures = testing.synthetic_textures(512, C, 4, 0)
+    unet_sd = testing.unet_state_dict(78 + 6 + C, 78, 64, 5, 0)
+    env = testing.synthetic_light_probe(1600, 3200, 2)[0]
+    l_dir = T(scene.sphere_samples(4096)).t().contiguous()
+    lp_model = network.LightingLP(l_dir, num_channel=3, lp_dataloader=[{'lp_img': env.permute(2, 0, 1)[None]}],
+                                  fix_params=True, device=DEV)             # default lp_img_h / lp_img_w = 1600 / 3200
+    assert tuple(lp_model.lps.shape) == (1, 1600, 3200, 3) and torch.equal(lp_model.lps[0].cpu(), env)
+    lp_model.fit_sh(lmax=10)
+    coeff = lp_model.sh_coeff.to(DEV)
+    # oracle: samples of the (identically resized) probe -> fit
+    uv = orc.spherical_mapping(l_dir)
+    samples = orc.interpolate_bilinear(env, (uv[0] * 3200.0).clamp(max=3199), (uv[1] * 1600.0).clamp(max=1599))
+    basis_l = torch.from_numpy(orc.sh_basis(10, l_dir.t().numpy()).astype(np.float32))
+    coeff_ref = orc.fit_sh_coeff(samples, basis_l)
+    assert (coeff[0].cpu() - coeff_ref).abs().max() < 2e-5
+    views = {k: T(v) for k, v in scene.spiral_views(S, [77]).items()}
+    dv = {k: v.to(DEV) for k, v in views.items()}
+    mk = lambda algo: RNRPipeline(mesh, S, textures, unet_sd, ps, pd, None, nf0=64, max_views=1, device=DEV, sh_coeff=coeff,
+                                  sh_lmax=10, skip_background_tiles=False, conv_algo=algo)
+    pipe = mk(None)
+    assert pipe.c_in == 100 and pipe.unet.in_c_pad == 112
+    img = pipe.render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'], keep_intermediates=True).clone()
+    last = pipe.last
+    algos = [pipe.unet.L.rnr_conv_algorithm(ctypes.byref(s['desc']), 1, *s['in_hw']) for s in pipe.unet.steps]
+    assert sum(a != 0 for a in algos) >= 19, algos                          # the product plan really is the Winograd one
+    direct = mk('direct').render(dv['proj'], dv['pose'], dv['proj_inv'], dv['R_inv'])
+    assert (img - direct).abs().max() <= 1e-5, (img - direct).abs().max()
+    del direct
+    # ---- integer maps: the oracle rasterizer on the kernel's own projected vertices
+    mesh_t = {k: torch.as_tensor(v) for k, v in mesh.items()}
+    gb = orc.rasterizer_forward(mesh_t, views['proj'], views['pose'], S, v_uvz_ndc=last['v_uvz'].cpu())
+    assert torch.equal(last['gb']['face_index_map'].cpu(), gb['face_index_map'])
+    assert torch.equal(last['gb']['alpha'].cpu(), gb['alpha'])
+    assert 0.2 < float(gb['alpha'].mean()) < 0.8
+    # ---- the whole frame on the CPU
+    basis = torch.from_numpy(orc.sh_basis(10, orc.lp_recon_dirs().numpy()).astype(np.float32))
+    lp = orc.reconstruct_lp(coeff_ref, basis)[None]
+    ref = orc.render_frame(mesh_t, views, S, textures, unet_sd, lp, ps, pd)
+    p = orc.psnr(img.cpu(), ref['image'])
+    assert p >= 60.0, p
 
 
 def test_background_tile_skip_is_invisible():

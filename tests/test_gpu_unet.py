@@ -727,7 +727,7 @@ FULL_SIZE_LAYERS = [
     (0, 512, [64], 64, 4),              # L2 / L21: conv_wino4_kernel, 4 chunks
     (0, 512, [64, 64], 78, 3),          # L22: the 80-column out layer (conv_wino80_kernel)
     (1, 512, [64], 128, 2),             # L3: 4x4 stride 2 (conv_wino2_kernel<1>)
-    (2, 256, [128, 128], 64, 2),        # L20: transposed 4x4 stride 2 over the skip concat (conv_wino2_kernel<2>)
+    (2, 256, [128, 128], 64, 2),        # L20: transposed 4x4 stride 2 over the skip concat (conv_wino2p_kernel<2>)
 ]
 
 
