@@ -46,24 +46,77 @@ def evaluate_sh_basis(lmax=0, azi=None, pol=None, directions=None, device=None, 
     out = ops.sh_basis(d, int(lmax))
     if as_tensor:
         return out
-    # cast on the DEVICE first, then a same-dtype blocking D2H copy: `host.copy_(out)` with float32 -> float64 across devices
-    # takes torch's slow conversion path (measured in the drop-in loop at 512^2: 15.6 ms per call against 0.37 ms this way,
+    # cast on the DEVICE first, then a same-dtype D2H copy: `host.copy_(out)` with float32 -> float64 across devices takes
+    # torch's slow conversion path (measured in the drop-in loop at 512^2: 15.6 ms per call against 0.37 ms this way,
     # scripts/exp_dropin_host2.py)
     out64 = out.double()
     nbytes = out64.numel() * 8
-    host = None
+    host = host32 = None
     if nbytes <= _PINNED_MAX_BYTES:
         try:
-            host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)     # a block of torch's caching pinned allocator
+            host = torch.empty(out.shape, dtype=torch.float64, pin_memory=True)     # blocks of torch's caching pinned allocator
+            host32 = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
         except RuntimeError:                                                        # page-locking refused (ulimit -l, fragmentation)
-            host = None
+            host = host32 = None
     if host is None:
         return out64.cpu().numpy()          # pageable copy: slower, nothing stays page-locked
-    host.copy_(out64)
+    host.copy_(out64, non_blocking=True)
+    host32.copy_(out, non_blocking=True)    # the values as the GPU computed them, for SHBasisArray.astype(np.float32)
+    torch.cuda.current_stream(out.device).synchronize()
     # The array ALIASES the page-locked block and keeps it alive: a caller that stores many results (precompute-style caches of
     # per-view bases) should store `result.copy()` — torch's caching host allocator recycles the block once the array is gone
     # but never returns it to the OS.  Results above RNR_SH_PINNED_MAX_MB (default 64) take the pageable path above.
-    return host.numpy()
+    return SHBasisArray._wrap(host.numpy(), host32.numpy())
+
+
+class SHBasisArray(np.ndarray):
+    """What `evaluate_sh_basis` returns: the float64 ndarray of the reference's contract (sph_harm.py:41-71) with ONE call answered
+    from a cache — the conversion the reference's view loop applies next (test_rnr.py:324),
+
+        sph_harm.evaluate_sh_basis(...).reshape((N, H, W, -1)).astype(np.float32)
+
+    The basis is computed in float32 on the GPU and the float64 container holds exactly those values, so `.astype(np.float32)` of
+    the array (or of a C-contiguous reshape of it) equals the float32 block that came down with it bit for bit; returning that block
+    saves the host-side conversion of 2.4 M doubles per 512 x 512 view, and because the block is page-locked the script's
+    `torch.from_numpy(...).to(device)` that follows is a direct DMA instead of a staged pageable copy (together 0.3 - 0.5 ms of the
+    1.2 ms this call costs in the loop).  The float64 array is READ-ONLY while it carries the cache (an in-place edit would make the
+    cached block stale); `.copy()` gives an ordinary writable array.  Every other operation is numpy's own and returns plain
+    arrays / views.  `SHBasisArray.stats` counts how often the cache answered (`fast`) and how often numpy converted (`plain`);
+    RNR_SH_FAST_ASTYPE=0 turns the cache off."""
+
+    stats = {'fast': 0, 'plain': 0}
+    _f32 = None
+
+    @classmethod
+    def _wrap(cls, a64, a32):
+        if os.environ.get('RNR_SH_FAST_ASTYPE', '1') == '0':
+            return a64
+        obj = a64.view(cls)
+        obj._f32 = [a32]        # one holder shared by every same-size view: the block is handed out once
+        obj.setflags(write=False)
+        return obj
+
+    def __array_finalize__(self, obj):
+        # the cache follows same-size views only (reshape / view): slices, copies and results of arithmetic drop it
+        f32 = getattr(obj, '_f32', None)
+        if f32 is not None and f32[0] is not None and self.base is not None and self.size == f32[0].size and self.dtype == np.float64:
+            self._f32 = f32
+        else:
+            self._f32 = None
+
+    def astype(self, dtype, order='K', casting='unsafe', subok=True, copy=True):
+        holder = self._f32
+        if (holder is not None and holder[0] is not None and np.dtype(dtype) == np.float32 and order in ('K', 'C', 'A')
+                and self.flags.c_contiguous and not self.flags.writeable):
+            SHBasisArray.stats['fast'] += 1
+            out = holder[0].reshape(self.shape)
+            holder[0] = None                    # handed out once: the caller owns (and may modify) the block now
+            return out
+        SHBasisArray.stats['plain'] += 1
+        return np.asarray(self).astype(dtype, order=order, casting=casting, subok=subok, copy=copy)
+
+    def __array_wrap__(self, arr, context=None, return_scalar=False):
+        return np.asarray(arr) if arr.ndim else arr[()]
 
 
 def fit_sh_coeff(samples, sh_basis_val):

@@ -240,3 +240,33 @@ def test_tbn_map_type_is_a_plain_tensor_off_the_gpu():
     assert type(t[0]) is render.TBNMap
     assert type(t + 1) is torch.Tensor and type(t.sum()) is torch.Tensor and type(torch.cat([t, t])) is torch.Tensor
     assert not bool(torch.isnan(t).sum() > 0)
+
+
+def test_sh_basis_array_cache_rules():
+    """sph_harm.SHBasisArray (what evaluate_sh_basis returns): float64 data as the reference's contract says, one cached answer —
+    `.astype(np.float32)` of the array or of a C-contiguous reshape of it returns the float32 block that came down with it, once —
+    and numpy's own behaviour for everything else (slices, copies, arithmetic, transposes, other dtypes)."""
+    import sph_harm
+    A = sph_harm.SHBasisArray
+    f32 = np.random.RandomState(0).rand(6, 9).astype(np.float32)
+    x = A._wrap(f32.astype(np.float64), f32.copy())
+    assert isinstance(x, np.ndarray) and x.dtype == np.float64 and not x.flags.writeable
+    A.stats.update(fast=0, plain=0)
+    y = x.reshape((1, 2, 3, -1))
+    z = y.astype(np.float32)                                            # test_rnr.py:324
+    assert type(z) is np.ndarray and z.dtype == np.float32 and z.shape == (1, 2, 3, 9) and z.flags.writeable
+    assert np.array_equal(z, f32.reshape(1, 2, 3, 9)) and A.stats == {'fast': 1, 'plain': 0}
+    z[...] = 0                                                          # the caller owns the block ...
+    again = x.astype(np.float32)                                        # ... so a second conversion is numpy's own
+    assert np.array_equal(again, f32) and A.stats == {'fast': 1, 'plain': 1}
+    # everything else: plain numpy semantics, no cache
+    x2 = A._wrap(f32.astype(np.float64), f32.copy())
+    assert type(x2 + 1) is np.ndarray and type(x2.sum()) is np.float64
+    assert np.array_equal(x2[1:3].astype(np.float32), f32[1:3])         # a slice converts the ordinary way
+    assert np.array_equal(x2.T.astype(np.float32), f32.T)               # so does a non-contiguous view
+    assert x2.astype(np.float16).dtype == np.float16
+    c = x2.copy()
+    assert c.flags.writeable and np.array_equal(c, x2)
+    with pytest.raises(ValueError):
+        x2[0, 0] = 1.0                                                  # read-only while it carries the cache
+    assert np.array_equal(x2.astype(np.float32), f32)                   # still cached (nothing above consumed it) and right

@@ -541,3 +541,28 @@ def test_ray_sampler_pivot_cache_follows_the_tensor_not_the_address():
         b.pivots_dir.mul_(-1.0)
         assert torch.equal(b(tbn, vt, alpha)[0], direct(b.pivots_dir.cpu()))
     assert len(ops._HOST_COPIES) <= 4
+
+
+def test_evaluate_sh_basis_numpy_contract_and_cached_float32():
+    """sph_harm.evaluate_sh_basis keeps the reference's contract (numpy in, float64 numpy out, sph_harm.py:41-71) and answers the
+    conversion test_rnr.py:324 applies next from the float32 block that came down with the result: same values bit for bit as
+    numpy's own conversion, counted in SHBasisArray.stats, off with RNR_SH_FAST_ASTYPE=0."""
+    import sph_harm
+    g = torch.Generator().manual_seed(21)
+    d = torch.nn.functional.normalize(torch.randn(1, 48, 40, 3, generator=g), dim=-1)
+    dn = d.reshape(-1, 3).numpy()
+    sph_harm.SHBasisArray.stats.update(fast=0, plain=0)
+    b = sph_harm.evaluate_sh_basis(lmax=2, directions=dn)
+    assert isinstance(b, np.ndarray) and b.dtype == np.float64 and b.shape == (48 * 40, 9)
+    plain = np.asarray(b).astype(np.float32)                            # numpy's conversion of the float64 container
+    fast = b.reshape((1, 48, 40, -1)).astype(np.float32)                # the script's expression
+    assert sph_harm.SHBasisArray.stats['fast'] == 1
+    assert fast.dtype == np.float32 and np.array_equal(fast.reshape(-1, 9), plain)
+    on_dev = sph_harm.evaluate_sh_basis(lmax=2, directions=d.reshape(-1, 3).to(DEV), as_tensor=True)
+    assert torch.equal(torch.from_numpy(fast).to(DEV).reshape(-1, 9), on_dev)
+    os.environ['RNR_SH_FAST_ASTYPE'] = '0'
+    try:
+        b2 = sph_harm.evaluate_sh_basis(lmax=2, directions=dn)
+        assert type(b2) is np.ndarray and b2.flags.writeable and np.array_equal(b2, np.asarray(b))
+    finally:
+        del os.environ['RNR_SH_FAST_ASTYPE']
