@@ -707,9 +707,17 @@ def main(argv=None):
     # whose allocator, code objects and clocks have seen nothing yet; W = 3..5 steps are 0.1 s.  Steps are rendered until
     # --prewarm-seconds have passed (host clock, synchronised) — the timed region below is untouched: exactly K steps.
     prewarm_steps = 0
-    if not stub and args.prewarm_seconds > 0:
+    prewarm_s = args.prewarm_seconds if not stub else min(args.prewarm_seconds, 0.2)      # the stub run only exercises the control flow
+    if prewarm_s > 0:
         tp = time.perf_counter()
-        while time.perf_counter() - tp < args.prewarm_seconds and prewarm_steps < 200:
+        while prewarm_steps < 200:
+            go = time.perf_counter() - tp < prewarm_s
+            if use_dist:        # every rank must run the same number of steps (each step is a collective): rank-agreed decision
+                flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                go = bool(flag.item())
+            if not go:
+                break
             step(prewarm_steps % max(1, args.warmup + args.steps))
             prewarm_steps += 1
             sync()
