@@ -239,7 +239,8 @@ def sustained_mfma_tflops():
     16-bit MFMAs clock down to 1.6 - 1.8 GHz under random data (power), so the nominal 2.5 PFLOP/s is not reachable by any
     kernel with live operands; the f32 MFMA holds 2.35 GHz.  Reported BESIDE the nominal-peak fractions, never instead."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_peak_micro.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_peak_micro.json')) +
+                   glob.glob(os.path.join(ROOT, 'profiles', 'archive', 'r*_mfma_peak_micro.json')), key=os.path.basename)
     if not files:
         return {}, None
     try:
@@ -504,7 +505,7 @@ def single_view_block(sc, args, dev):
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
         'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2p_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view; the split-K Winograd layers are '
                                                   'followed by a reduce launch and the one-workgroup-per-CU grids by a BatchNorm finalise launch of their own: '
-                                                  '12 + 13 launches at 512^2, profiles/r04_frame_timeline_f32_views1.txt; HIP events bracket the U-Net stage of every call)',
+                                                  '12 + 13 launches at 512^2, profiles/r06_frame_timeline_f32_views1.txt; HIP events bracket the U-Net stage of every call)',
                      **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
                      'alg_flops_per_view': flops_view, 'traffic': traffic,
                      'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
@@ -1076,7 +1077,7 @@ def main(argv=None):
                                   'v_mfma_f32_32x32x16_bf16'),
                     ('f16x3', 3, 'every conv operand split into 2 fp16 terms (22 significand bits, weights pre-scaled per layer by '
                                  'a power of two), 3 partial products accumulated in fp32 on v_mfma_f32_32x32x16_f16; error vs '
-                                 'float64 0.32-0.87x the exact-fp32 kernels on 21 of 22 layer shapes, 1.01x on the last (profiles/r02_emu_layer_table.md)')]:
+                                 'float64 0.32-0.87x the exact-fp32 kernels on 21 of 22 layer shapes, 1.01x on the last (profiles/archive/r02_emu_layer_table.md)')]:
                 pe = make_pipeline(sc, args, dev, V, skip_background_tiles=False, precision=prec)
                 emu_img = pe.render(poses['proj'][sl], poses['pose'][sl], poses['proj_inv'][sl], poses['R_inv'][sl])
                 diff = float((emu_img - native).abs().max())

@@ -1050,7 +1050,7 @@ conv_halo_kernel(const ConvParams P) {
 }
 
 // (r03 experiment, measured and not adopted: conv_halo_kernel as a persistent tile loop with next-tile prefetch — -1.4 % at 8
-// views per launch, DESIGN.md §3.3, profiles/r03_layer_time_persist_ab_*.  The source is kept outside the product tree:
+// views per launch, DESIGN.md §3.3, profiles/archive/r03_layer_time_persist_ab_*.  The source is kept outside the product tree:
 // scripts/experiments/conv_persist_experiment.inc, with the three inclusion points it needs.)
 
 // ------------------------------------------------------------------------------------------------

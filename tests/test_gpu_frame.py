@@ -242,7 +242,7 @@ def test_frame512_nf64_16_view_plan_vs_oracle():
 def test_frame512_conv_algorithms_agree():
     """The gate behind the default conv_algo, as a regression test on six views of the bench
     workload: frames of the F(4x4, 3x3) product path ('winograd4'), of the F(2x2, .)-only path ('winograd') and of the direct
-    path agree to 1e-5 (measured over all 720 views: <= 1.8e-6, profiles/r04_winograd4_vs_direct_720views.json), at 8-view,
+    path agree to 1e-5 (measured over all 720 views: <= 1.8e-6, profiles/archive/r04_winograd4_vs_direct_720views.json), at 8-view,
     2-view and one-view calls (different plans: split grids at the small view counts), and every path is bit-stable run to run."""
     import ctypes
     from rnr_amd import scene
