@@ -52,6 +52,11 @@ def test_bench_control_flow_world2_gloo(V, steps, warm):
         assert 'with_8_views_per_gpu' not in res
     # value is the whole-job aggregate over both ranks on the MAX-reduced time
     assert abs(res['value'] - steps * 2 * V / (res['ms_per_step'] * 1e-3 * steps)) < 1e-6 * res['value']
+    # r06: the value is one window of EXACTLY `steps` steps (the stub runs a single window), listed with its policy, and the line
+    # carries the per-step series (host enqueue times on the stub; HIP-event intervals on a GPU) and the agreed pre-warm count
+    assert 'exactly %d steps' % steps in res['value_policy'] and len(res['windows']) == 1 and res['windows'][0]['is_value'] is True
+    assert abs(res['windows'][0]['frames_per_s'] - res['value']) < 1e-9 * res['value']
+    assert len(res['step_series']['host_enqueue_ms']) == steps and res['prewarm_steps'] >= 1
     gc = res['gather_check']
     assert gc['ok'] is True and gc['ranks_with_mismatch'] == 0 and gc['backend'] == 'gloo'
     assert gc['gathered_shape'] == [2 * V, 3, 16, 16]

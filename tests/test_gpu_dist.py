@@ -33,6 +33,14 @@ def test_bench_under_torchrun_rccl_gather():
     assert res['gather_check']['gathered_shape'] == [2, 3, 512, 512]
     assert res['value'] > 10.0 and res['scaling'] == 'weak'
     assert 0.1 < res['roofline']['frac'] <= 1.0 and res['cpu_baseline'] is None and res['n_ranks_seen'] == 1
+    # r06: three windows of exactly K steps, value = the median one, and its per-step attribution (HIP events on the launch stream)
+    ws = res['windows']
+    assert len(ws) == 3 and sum(w['is_value'] for w in ws) == 1 and 'median of 3' in res['value_policy']
+    assert sorted(w['frames_per_s'] for w in ws)[1] == [w for w in ws if w['is_value']][0]['frames_per_s'] == res['value']
+    ss = res['step_series']
+    assert len(ss['step_ms']) == 2 and len(ss['gap_ms']) == 1 and len(ss['unet_ms']) == 2 and len(ss['host_enqueue_ms']) == 2
+    assert all(u < t for u, t in zip(ss['unet_ms'], ss['step_ms'])) and ss['ms_per_step_min'] <= ss['ms_per_step_median'] <= ss['ms_per_step_max']
+    assert ss['non_unet_ms_per_step'] > 0 and isinstance(ss['slow_steps'], list) and res['prewarm_steps'] >= 1
 
 
 def test_bench_plain_launch_forced_dist():
