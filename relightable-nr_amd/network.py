@@ -283,7 +283,8 @@ class LightingSH(nn.Module):
         self.num_sample, self.lmax, self.num_basis = l_dir.shape[1], lmax, (lmax + 1) ** 2
         self.num_lighting, self.num_channel, self.fix_params = num_lighting, num_channel, fix_params
         self.lp_recon_h, self.lp_recon_w = lp_recon_h, lp_recon_w
-        basis = torch.from_numpy(sph_harm.evaluate_sh_basis(lmax=lmax, directions=l_dir.detach().cpu().numpy().transpose()))
+        # (network.py:557 goes through numpy; the values are the same float32 numbers, kept on the way as a tensor)
+        basis = sph_harm.evaluate_sh_basis(lmax=lmax, directions=l_dir.detach().cpu().numpy().transpose(), as_tensor=True)
         self.register_buffer('basis_val', basis.to(l_dir.dtype).to(l_dir.device))
         self.coeff = nn.Parameter(torch.zeros((num_lighting, self.num_basis, num_channel), dtype=torch.float32))
         if init_coeff is not None:
@@ -297,7 +298,7 @@ class LightingSH(nn.Module):
                                 torch.arange(lp_recon_w, dtype=torch.float32) / (lp_recon_w - 1), indexing='ij')
         dirs = render.spherical_mapping_inv(torch.stack([uu, vv]).flatten(1)).permute(1, 0).numpy()
         self.register_buffer('basis_val_recon',
-                             torch.from_numpy(sph_harm.evaluate_sh_basis(lmax=lmax, directions=dirs)).to(l_dir.dtype))
+                             sph_harm.evaluate_sh_basis(lmax=lmax, directions=dirs, as_tensor=True).cpu().to(l_dir.dtype))
 
     def forward(self, lighting_idx=None, coeff=None, is_lp=None):
         if coeff is not None:
