@@ -128,10 +128,15 @@ __device__ __forceinline__ bool face_setup(long i, const float* __restrict__ fac
     if (!finite || !(sin_min > 0.0) || !(pad_px <= 16.0)) {
         box.xlo = BOX_EXACT; box.xhi = (short)(is - 1); box.ylo = 0; box.yhi = (short)(is - 1);
     } else {
-        double lx = floor(((minx - pad_ndc) * is + is - 1) * 0.5) - 1.0;
-        double hx = ceil(((maxx + pad_ndc) * is + is - 1) * 0.5) + 1.0;
-        double ly = floor(((miny - pad_ndc) * is + is - 1) * 0.5) - 1.0;
-        double hy = ceil(((maxy + pad_ndc) * is + is - 1) * 0.5) + 1.0;
+        // pixel i has its centre at NDC (2i + 1 - is) / is, i.e. NDC x is the pixel coordinate (x * is + is - 1) / 2: the pixels
+        // whose centre lies within pad_ndc (>= 10 x the proven distance bound) of the face's extent are exactly
+        // [ceil(lo), floor(hi)].  (Until r06 the box carried up to four further pixels per side — the +1 of pad_px, which
+        // belongs to the trust criterion above, a -1 / +1 here, and floor / ceil the other way round — and a pixel-sized face
+        // of the 65 536-face sphere walked 80 pixels instead of 30.)
+        double lx = ceil(((minx - pad_ndc) * is + is - 1) * 0.5);
+        double hx = floor(((maxx + pad_ndc) * is + is - 1) * 0.5);
+        double ly = ceil(((miny - pad_ndc) * is + is - 1) * 0.5);
+        double hy = floor(((maxy + pad_ndc) * is + is - 1) * 0.5);
         lx = fmax(lx, 0.0); ly = fmax(ly, 0.0);
         hx = fmin(hx, (double)(is - 1)); hy = fmin(hy, (double)(is - 1));
         if (lx > hx || ly > hy) {
@@ -196,11 +201,30 @@ __device__ __forceinline__ void bin_append(int* tile_count, int* tile_list, int 
     const int slot = atomicAdd(tile_count + tile, 1);
     if (slot < BIN_CAP) tile_list[(size_t)tile * BIN_CAP + slot] = fn;
 }
+// The same test on the six coordinates of a wide-list record (below).
+__device__ __forceinline__ bool coords_may_touch_tile(float x0, float y0, float x1, float y1, float x2, float y2, float xlo,
+                                                      float xhi, float ylo, float yhi) {
+    return !(edge_rejects_tile(x0, y0, x1, y1, xlo, xhi, ylo, yhi) || edge_rejects_tile(x1, y1, x2, y2, xlo, xhi, ylo, yhi) ||
+             edge_rejects_tile(x2, y2, x0, y0, xlo, xhi, ylo, yhi));
+}
+// A face on the wide list leaves, beside its index, the record every tile tests: (x0, y0, x1, y1) (x2, y2, face index, -) —
+// two 16-byte loads at consecutive addresses per lane, where the tile kernel used to chase index -> box -> nine floats at
+// a stride of 36 bytes through three dependent round trips per 256 wide faces (the 65 536-face sphere has 520 of them, its
+// zero-area pole faces: 42 of the tile kernel's 52 us at one view per call, r06).
+constexpr int WIDE_REC_FLOATS = 8;
+__device__ __forceinline__ void wide_append(int* wide_count, int* wide_list, float* wide_rec, int bn, int nf, int fn, float x0,
+                                            float y0, float x1, float y1, float x2, float y2) {
+    const int pos = atomicAdd(wide_count + bn, 1);
+    wide_list[(size_t)bn * nf + pos] = fn;
+    float4* r = reinterpret_cast<float4*>(wide_rec + ((size_t)bn * nf + pos) * WIDE_REC_FLOATS);
+    r[0] = make_float4(x0, y0, x1, y1);
+    r[1] = make_float4(x2, y2, __builtin_bit_cast(float, fn), 0.0f);
+}
 
 __global__ void __launch_bounds__(256)
 bin_faces_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ boxes, int* __restrict__ tile_count,
-                 int* __restrict__ tile_list, int* __restrict__ wide_count, int* __restrict__ wide_list, int batch,
-                 int nf, int is) {
+                 int* __restrict__ tile_list, int* __restrict__ wide_count, int* __restrict__ wide_list,
+                 float* __restrict__ wide_rec, int batch, int nf, int is) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)batch * nf) return;
     const int bn = (int)(i / nf), fn = (int)(i % nf);
@@ -209,12 +233,11 @@ bin_faces_kernel(const float* __restrict__ faces, const FaceBox* __restrict__ bo
     const int tiles_x = (is + TILE - 1) / TILE;
     const int ntiles = tiles_x * tiles_x;
     const int txa = max(b.xlo, (short)0) / TILE, txb = b.xhi / TILE, tya = max(b.ylo, (short)0) / TILE, tyb = b.yhi / TILE;
+    const float* f = faces + i * 9;
     if (b.xlo == BOX_EXACT || (txb - txa + 1) * (tyb - tya + 1) > WIDE_TILES) {
-        const int pos = atomicAdd(wide_count + bn, 1);
-        wide_list[(size_t)bn * nf + pos] = fn;
+        wide_append(wide_count, wide_list, wide_rec, bn, nf, fn, f[0], f[1], f[3], f[4], f[6], f[7]);
         return;
     }
-    const float* f = faces + i * 9;
     int* tc = tile_count + (size_t)bn * ntiles;
     int* tl = tile_list + (size_t)bn * ntiles * BIN_CAP;
     for (int ty = tya; ty <= tyb; ty++)
@@ -266,12 +289,43 @@ __device__ __forceinline__ bool cand_depth(const float4 r3, const float4 r4, con
 constexpr int SPLAT_MAX_PIX = 256;
 constexpr unsigned long long KEY_EMPTY = ~0ull;
 
+// The pixel walk of one face.  A row is scanned in 32-column pieces: first the cheap inside tests of the piece (a bit per
+// pixel), then the depth arithmetic — seven correctly rounded divisions — for the set bits only: a wave then runs it as
+// often as its busiest lane has inside pixels, not once per column in which ANY lane is inside.
+// POW2: `is` is a power of two, where (2i + 1 - is) / is == (2i + 1 - is) * (1 / is) exactly (both are exact), without the
+// division sequence per pixel.
+template <bool POW2>
+__device__ __forceinline__ void splat_pixels(const float4 r0, const float4 r1, const float4 r2, const float4 r3, const float4 r4,
+                                             const float4 r5, int xa, int xb, int ya, int yb, int fn,
+                                             unsigned long long* __restrict__ kv, int is, float near_, float far_) {
+    const float inv_is = 1.0f / (float)is;
+    auto center = [&](int i) { return POW2 ? (float)(2 * i + 1 - is) * inv_is : pix_center(i, is); };
+    for (int yi = ya; yi <= yb; yi++) {
+        const float yp = center(yi);
+        for (int xc = xa; xc <= xb; xc += 32) {
+            const int xe = min(xb, xc + 31);
+            unsigned m = 0u;
+            for (int xi = xc; xi <= xe; xi++)
+                if (cand_inside(r0, r1, r2, center(xi), yp)) m |= 1u << (xi - xc);
+            while (m) {
+                const int xi = xc + __builtin_ctz(m);
+                m &= m - 1u;
+                float zp, w0, w1, w2;
+                if (!cand_depth(r3, r4, r5, (float)xi, (float)yi, near_, far_, zp, w0, w1, w2)) continue;
+                if (!(zp > 0.0f)) continue;                             // NaN (and anything the bit order cannot rank)
+                const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, zp) << 32) | (unsigned)fn;
+                atomicMin(kv + (size_t)yi * is + xi, key);
+            }
+        }
+    }
+}
+
 // f / fi: the face's 9 + 9 floats (global memory or the registers of the setup that has just produced them)
 template <typename FP>
 __device__ __forceinline__ void splat_face(long i, int bn, int fn, const FaceBox b, FP f, FP fi,
                                            unsigned long long* __restrict__ keys, int* __restrict__ tile_count,
                                            int* __restrict__ tile_list, int* __restrict__ wide_count, int* __restrict__ wide_list,
-                                           int nf, int is, float near_, float far_) {
+                                           float* __restrict__ wide_rec, int nf, int is, float near_, float far_) {
     if (b.xlo != BOX_EXACT && b.xlo > b.xhi) return;                    // empty_box(): culled / off-screen
     const int xa = max((int)b.xlo, 0), xb = b.xhi, ya = max((int)b.ylo, 0), yb = b.yhi;
     if (b.xlo == BOX_EXACT || (xb - xa + 1) * (yb - ya + 1) > SPLAT_MAX_PIX) {
@@ -288,8 +342,7 @@ __device__ __forceinline__ void splat_face(long i, int bn, int fn, const FaceBox
                     if (face_may_touch_tile(f, tx, ty, is)) bin_append(tc, tl, ty * tiles_x + tx, fn);
             return;
         }
-        const int pos = atomicAdd(wide_count + bn, 1);
-        wide_list[(size_t)bn * nf + pos] = fn;
+        wide_append(wide_count, wide_list, wide_rec, bn, nf, fn, f[0], f[1], f[3], f[4], f[6], f[7]);
         return;
     }
     const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
@@ -300,28 +353,19 @@ __device__ __forceinline__ void splat_face(long i, int bn, int fn, const FaceBox
     const float4 r4 = make_float4(fi[4], fi[5], fi[6], fi[7]);
     const float4 r5 = make_float4(fi[8], z0, z1, z2);
     unsigned long long* kv = keys + (size_t)bn * is * is;
-    for (int yi = ya; yi <= yb; yi++) {
-        const float yp = pix_center(yi, is);
-        for (int xi = xa; xi <= xb; xi++) {
-            const float xp = pix_center(xi, is);
-            if (!cand_inside(r0, r1, r2, xp, yp)) continue;
-            float zp, w0, w1, w2;
-            if (!cand_depth(r3, r4, r5, (float)xi, (float)yi, near_, far_, zp, w0, w1, w2)) continue;
-            if (!(zp > 0.0f)) continue;                                 // NaN (and anything the bit order cannot rank)
-            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, zp) << 32) | (unsigned)fn;
-            atomicMin(kv + (size_t)yi * is + xi, key);
-        }
-    }
+    if ((is & (is - 1)) == 0) splat_pixels<true>(r0, r1, r2, r3, r4, r5, xa, xb, ya, yb, fn, kv, is, near_, far_);
+    else splat_pixels<false>(r0, r1, r2, r3, r4, r5, xa, xb, ya, yb, fn, kv, is, near_, far_);
 }
 
 __global__ void __launch_bounds__(256)
 splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ faces_inv, const FaceBox* __restrict__ boxes,
                    unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
-                   int* __restrict__ wide_count, int* __restrict__ wide_list, int batch, int nf, int is, float near_, float far_) {
+                   int* __restrict__ wide_count, int* __restrict__ wide_list, float* __restrict__ wide_rec, int batch, int nf,
+                   int is, float near_, float far_) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)batch * nf) return;
     splat_face<const float*>(i, (int)(i / nf), (int)(i % nf), boxes[i], faces + i * 9, faces_inv + i * 9, keys, tile_count,
-                             tile_list, wide_count, wide_list, nf, is, near_, far_);
+                             tile_list, wide_count, wide_list, wide_rec, nf, is, near_, far_);
 }
 
 // face_setup_kernel + splat_faces_kernel in one launch (r04): both are one lane per (view, face) and the splat needs nothing
@@ -333,15 +377,15 @@ __global__ void __launch_bounds__(256)
 setup_splat_faces_kernel(const float* __restrict__ faces_in, const float* __restrict__ v_uvz, const int32_t* __restrict__ fidx,
                          float* __restrict__ faces_out, float* __restrict__ faces_inv, FaceBox* __restrict__ boxes,
                          unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
-                         int* __restrict__ wide_count, int* __restrict__ wide_list, int batch, int nf, int nv, int is,
-                         float near_, float far_) {
+                         int* __restrict__ wide_count, int* __restrict__ wide_list, float* __restrict__ wide_rec, int batch,
+                         int nf, int nv, int is, float near_, float far_) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)batch * nf) return;
     float f[9], inv[9];
     FaceBox box;
     if (!face_setup<GATHER>(i, faces_in, v_uvz, fidx, faces_out, faces_inv, boxes, nf, nv, is, f, inv, box)) return;
     splat_face<const float (&)[9]>(i, (int)(i / nf), (int)(i % nf), box, f, inv, keys, tile_count, tile_list, wide_count,
-                                   wide_list, nf, is, near_, far_);
+                                   wide_list, wide_rec, nf, is, near_, far_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,6 +400,7 @@ struct RasterParams {
     const unsigned long long* keys;   // [B,is,is] winners of the face-parallel path (KEY_EMPTY = none) or NULL
     const int* wide_count;   // [B] faces on the wide list: untrusted or huge boxes, tested by every tile itself
     const int* wide_list;    // [B,nf]
+    const float* wide_rec;   // [B,nf,WIDE_REC_FLOATS] what the tiles test of a wide face (wide_append)
     int nf, is;
     float near_, far_;
     int flip;                // 1: write row (is-1-yi)
@@ -376,6 +421,8 @@ raster_tile_kernel(const RasterParams P) {
     __shared__ int s_queue[QCAP];
     __shared__ __attribute__((aligned(16))) float s_stage[STAGE * STAGE_FLOATS];
     __shared__ int s_qn;
+    __shared__ int s_dn;                                // zero-area wide faces queued from the END of s_queue (walk_lines)
+    __shared__ unsigned long long s_key[RTHREADS];      // their per-pixel winners: the same (depth bits, face) key as P.keys
 
     const int is = P.is, nf = P.nf;
     const int tiles_x = (is + TILE - 1) / TILE;
@@ -400,7 +447,12 @@ raster_tile_kernel(const RasterParams P) {
     int best = -1;
     float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
 
-    if (tid == 0) s_qn = 0;
+    // the face-parallel path's winner of this pixel, requested up front: independent of everything the lists below need
+    unsigned long long key = KEY_EMPTY;
+    if (P.keys && in_img) key = P.keys[((size_t)bn * is + yi) * is + xi];
+
+    if (tid == 0) { s_qn = 0; s_dn = 0; }
+    s_key[tid] = KEY_EMPTY;
     __syncthreads();
 
     // Evaluate the queued candidates.  The queue is NOT in face order (waves append independently), so the
@@ -452,32 +504,143 @@ raster_tile_kernel(const RasterParams P) {
     // the wide list (untrusted boxes, faces over more than WIDE_TILES tiles): every tile tests it against itself — usually
     // empty, and then this costs one scalar load where bin_wide_kernel cost a launch (r04).  A tile that rescans every face
     // anyway (overflowed list) meets the wide faces there.
-    if (P.wide_count && binned <= BIN_CAP) {
-        const int wn = P.wide_count[bn];
-        const int* wl = P.wide_list + (size_t)bn * nf;
-        for (int w0 = 0; w0 < wn; w0 += RTHREADS) {
-            const int w = w0 + tid;
-            bool k = false;
-            int fn = 0;
-            if (w < wn) {
-                fn = wl[w];
-                const FaceBox b = boxes[fn];
-                if (b.xlo == BOX_EXACT || (b.xlo <= tx1 && b.xhi >= tx0 && b.ylo <= ty1 && b.yhi >= ty0))     // a big but trustworthy box still prunes
-                    k = face_may_touch_tile(faces + (size_t)fn * 9, tile % tiles_x, tile / tiles_x, is);
+    // Zero-area wide faces (two coincident vertices: the pole faces of a UV sphere, 520 of the 65 536-face bench mesh).  Their
+    // pass region is a line: with the distinct vertices a, b the reference's three edge tests reduce to  P1 >= Q1  and
+    // P2 <= Q2, rounded evaluations of the same edge function E(p) = (yp - ya) dx - (xp - xa) dy  (dx = fl(xb - xa), dy alike;
+    // the opposite edge has exactly the negated differences), so a pixel can only pass with |E(p)| <= 2.01 u (|yp - ya| |dx| +
+    // |xp - xa| |dy|) + 2 u |dx dy|.  With every coordinate in [-4, 4] that puts the pixel centre within 36 u = 2.2e-6 NDC of
+    // the line along the axis the line is steeper in — 0.018 pixels at the largest image the library accepts (16384).  So of
+    // each pixel row (column, for a shallow line) of the tile only the two pixels next to the crossing can pass; they get the
+    // reference's candidate arithmetic (cand_inside / cand_depth: the same bits as everywhere else), 32 tests per (tile, face)
+    // instead of 256, sixteen faces at a time, and the result is folded into a per-pixel key like the splat path's.  A tile at
+    // a pole of the sphere holds ~260 such candidates: 36 us as ordinary queue entries at one view per call, r06.
+    // Faces outside the conditions (three coincident vertices, |coordinate| > 4, |b - a| < 1e-6, near < 0) stay ordinary.
+    // what the walk needs of a zero-area face, 12 floats: (x0, y0, x1, y1) (x2, y2, face, steep) and, as doubles, (c0, c1): the
+    // crossing of row / column i with the line, in pixel coordinates, is c0 + c1 * pix_center(i)
+    constexpr int LINE_FLOATS = 12;
+    static_assert(RTHREADS * LINE_FLOATS <= STAGE * STAGE_FLOATS, "a batch of line records fits the staging array");
+    auto stage_line = [&](int slot, const float4 ra, const float4 rb) {
+        const float x0 = ra.x, y0 = ra.y, x1 = ra.z, y1 = ra.w, x2 = rb.x, y2 = rb.y;
+        // the two distinct points: v0 and v1, or v0 and v2 when v0 == v1
+        const bool e01 = x0 == x1 && y0 == y1;
+        const float xa = x0, ya = y0, xb = e01 ? x2 : x1, yb = e01 ? y2 : y1;
+        const float dx = xb - xa, dy = yb - ya;
+        const bool steep = fabsf(dy) >= fabsf(dx);
+        // steep: x(yp) = xa + (yp - ya) dx / dy, else y(xp) = ya + (xp - xa) dy / dx; NDC t -> pixel coordinate (t * is + is - 1) / 2
+        const double sl = steep ? (double)dx / (double)dy : (double)dy / (double)dx;
+        const double t0 = steep ? (double)xa - (double)ya * sl : (double)ya - (double)xa * sl;
+        const double c0 = (t0 * is + is - 1) * 0.5, c1 = sl * is * 0.5;
+        float4* dst = reinterpret_cast<float4*>(s_stage + slot * LINE_FLOATS);
+        dst[0] = ra;
+        dst[1] = make_float4(x2, y2, rb.z, steep ? 1.0f : 0.0f);
+        reinterpret_cast<double2*>(dst)[2] = make_double2(c0, c1);
+    };
+    const bool pow2 = (is & (is - 1)) == 0;
+    const float inv_is = 1.0f / (float)is;
+    // pix_center without the division where `is` is a power of two (both forms are exact there)
+    auto center = [&](int i) { return pow2 ? (float)(2 * i + 1 - is) * inv_is : pix_center(i, is); };
+    // The first RTHREADS records were staged by the lanes that queued them (registers -> LDS, no second fetch); later batches
+    // are fetched again by their slot number.
+    auto walk_lines = [&](int dn) {
+        for (int d0 = 0; d0 < dn; d0 += RTHREADS) {
+            const int n = min(RTHREADS, dn - d0);
+            if (d0 > 0) {
+                if (tid < n) {
+                    const int w = s_queue[QCAP - 1 - (d0 + tid)];
+                    const float4* r = reinterpret_cast<const float4*>(P.wide_rec + ((size_t)bn * nf + w) * WIDE_REC_FLOATS);
+                    stage_line(tid, r[0], r[1]);
+                }
+                __syncthreads();
             }
-            const unsigned long long bal = __ballot(k);
-            if (bal) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_qn, __popcll(bal));
-                base = __shfl(base, 0, 64);
-                if (k) s_queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = fn;
+            const int sub = tid & 15;
+            for (int c = tid >> 4; c < n; c += RTHREADS / 16) {
+                const float4* rec = reinterpret_cast<const float4*>(s_stage + c * LINE_FLOATS);
+                const float4 ra = rec[0], rb = rec[1];
+                const double2 cc = reinterpret_cast<const double2*>(rec)[2];
+                const float x0 = ra.x, y0 = ra.y, x1 = ra.z, y1 = ra.w, x2 = rb.x, y2 = rb.y;
+                const int fn = __builtin_bit_cast(int, rb.z);
+                const bool steep = rb.w != 0.0f;
+                // the crossing of this lane's row (steep) or column with the line, in pixel coordinates
+                const int fixed = (steep ? ty0 : tx0) + sub;
+                const float cf = center(fixed);
+                const double tp = cc.x + cc.y * (double)cf;
+                if (!(tp > -2.0 && tp < (double)is + 1.0)) continue;
+                const int lo = (int)floor(tp);
+                const float4 r0 = make_float4(x0, y0, x1, y1);
+                const float4 r1 = make_float4(x2, y2, x1 - x0, y1 - y0);
+                const float4 r2 = make_float4(x2 - x1, y2 - y1, x0 - x2, y0 - y2);
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const int pxi = steep ? lo + side : fixed, pyi = steep ? fixed : lo + side;
+                    if (pxi < tx0 || pxi > tx1 || pyi < ty0 || pyi > ty1) continue;
+                    if (!cand_inside(r0, r1, r2, steep ? center(pxi) : cf, steep ? cf : center(pyi))) continue;
+                    const float* f = faces + (size_t)fn * 9;
+                    const float* fi = faces_inv + (size_t)fn * 9;
+                    float zp, w0, w1, w2;
+                    if (!cand_depth(make_float4(fi[0], fi[1], fi[2], fi[3]), make_float4(fi[4], fi[5], fi[6], fi[7]),
+                                    make_float4(fi[8], f[2], f[5], f[8]), (float)pxi, (float)pyi, P.near_, P.far_, zp, w0, w1, w2))
+                        continue;
+                    if (!(zp > 0.0f)) continue;         // NaN (never wins) — and the key order needs zp > 0 (near >= 0 here)
+                    atomicMin(&s_key[(pyi - ty0) * TILE + (pxi - tx0)],
+                              ((unsigned long long)__builtin_bit_cast(unsigned, zp) << 32) | (unsigned)fn);
+                }
             }
             __syncthreads();
-            const int qn = s_qn;
-            __syncthreads();        // every wave has read s_qn before any wave's next append: the flush decision IS block-uniform
-            if (qn > QCAP - RTHREADS || w0 + RTHREADS >= wn) {
+        }
+    };
+    if (P.wide_count && binned <= BIN_CAP) {
+        const int wn = P.wide_count[bn];
+        const float4* wr = reinterpret_cast<const float4*>(P.wide_rec + (size_t)bn * nf * WIDE_REC_FLOATS);
+        // WIDE_ITEMS records per lane and round, all of a round's loads in flight together: one round trip and one barrier
+        // pair per 1024 wide faces
+        constexpr int WIDE_ITEMS = 4;
+        for (int w0 = 0; w0 < wn; w0 += RTHREADS * WIDE_ITEMS) {
+            float4 ra[WIDE_ITEMS], rb[WIDE_ITEMS];
+#pragma unroll
+            for (int j = 0; j < WIDE_ITEMS; j++) {
+                const int w = w0 + j * RTHREADS + tid;
+                if (w < wn) { ra[j] = wr[2 * w]; rb[j] = wr[2 * w + 1]; }
+            }
+#pragma unroll
+            for (int j = 0; j < WIDE_ITEMS; j++) {
+                const int w = w0 + j * RTHREADS + tid;
+                if (w0 + j * RTHREADS >= wn) break;                     // block-uniform
+                const bool k = w < wn && coords_may_touch_tile(ra[j].x, ra[j].y, ra[j].z, ra[j].w, rb[j].x, rb[j].y, t_xlo, t_xhi,
+                                                               t_ylo, t_yhi);
+                bool line = false;
+                if (k && P.keys) {      // (P.keys: near >= 0)
+                    const float x0 = ra[j].x, y0 = ra[j].y, x1 = ra[j].z, y1 = ra[j].w, x2 = rb[j].x, y2 = rb[j].y;
+                    const int ne = (x0 == x1 && y0 == y1 ? 1 : 0) + (x1 == x2 && y1 == y2 ? 1 : 0) + (x2 == x0 && y2 == y0 ? 1 : 0);
+                    const float amax = fmaxf(fmaxf(fmaxf(fabsf(x0), fabsf(y0)), fmaxf(fabsf(x1), fabsf(y1))), fmaxf(fabsf(x2), fabsf(y2)));
+                    const float ex = (x0 == x1 && y0 == y1) ? x2 - x0 : x1 - x0, ey = (x0 == x1 && y0 == y1) ? y2 - y0 : y1 - y0;
+                    line = ne == 1 && amax <= 4.0f && fmaxf(fabsf(ex), fabsf(ey)) >= 1e-6f;
+                }
+                const unsigned long long bal = __ballot(k && !line);
+                if (bal) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_qn, __popcll(bal));
+                    base = __shfl(base, 0, 64);
+                    if (k && !line) s_queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = __builtin_bit_cast(int, rb[j].z);
+                }
+                const unsigned long long bld = __ballot(line);
+                if (bld) {              // the record's slot number, from the end of the queue
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_dn, __popcll(bld));
+                    base = __shfl(base, 0, 64);
+                    if (line) {
+                        const int slot = base + __popcll(bld & ((1ull << lane) - 1ull));
+                        s_queue[QCAP - 1 - slot] = w;
+                        if (slot < RTHREADS) stage_line(slot, ra[j], rb[j]);
+                    }
+                }
+            }
+            __syncthreads();
+            const int qn = s_qn, dn = s_dn;
+            __syncthreads();        // every wave has read the counts before any wave's next append: the flush decision IS block-uniform
+            if (qn + dn > QCAP - RTHREADS * WIDE_ITEMS || w0 + RTHREADS * WIDE_ITEMS >= wn) {
+                walk_lines(dn);                                    // first: it reads the staging array this round filled; ends with a barrier
                 process_queue(s_queue, qn);                        // ends with a barrier
-                if (tid == 0) s_qn = 0;
+                if (tid == 0) { s_qn = 0; s_dn = 0; }
                 __syncthreads();
             }
         }
@@ -532,8 +695,8 @@ raster_tile_kernel(const RasterParams P) {
     }
 
     if (!in_img) return;
-    if (P.keys) {       // winner of the face-parallel path for this pixel: same rule (smallest zp, then smallest face index)
-        const unsigned long long key = P.keys[((size_t)bn * is + yi) * is + xi];
+    {                   // winner of the face-parallel paths for this pixel: same rule (smallest zp, then smallest face index)
+        key = min(key, s_key[tid]);     // (walk_lines ended with a barrier; the key order IS that rule)
         if (key != KEY_EMPTY) {
             const float kz = __builtin_bit_cast(float, (unsigned)(key >> 32));
             const int kf = (int)(unsigned)(key & 0xffffffffull);
@@ -700,9 +863,11 @@ static int num_tiles(int is) { const int t = (is + TILE - 1) / TILE; return t * 
 // binning scratch: [tile_count B*ntiles | wide_count B] (zeroed every call) | tile_list | wide_list
 static size_t bin_counter_bytes(int batch, int is) { return align_up((size_t)batch * (num_tiles(is) + 1) * sizeof(int), 256); }
 static size_t key_bytes(int batch, int is) { return align_up((size_t)batch * is * is * sizeof(unsigned long long), 256); }
+static size_t wide_rec_bytes(int batch, int nf) { return align_up((size_t)batch * nf * WIDE_REC_FLOATS * sizeof(float), 256); }
+// ... | keys | wide records (behind everything earlier rounds laid out: gbuffer_clear_regions' offsets are unchanged)
 static size_t bin_bytes(int batch, int nf, int is) {
     return bin_counter_bytes(batch, is) + align_up((size_t)batch * num_tiles(is) * BIN_CAP * sizeof(int), 256) +
-           align_up((size_t)batch * nf * sizeof(int), 256) + key_bytes(batch, is);
+           align_up((size_t)batch * nf * sizeof(int), 256) + key_bytes(batch, is) + wide_rec_bytes(batch, nf);
 }
 
 // Small trusted faces are resolved face-parallel into P.keys (near >= 0), everything else is binned into the tile lists;
@@ -729,6 +894,7 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(
         ws + bin_counter_bytes(batch, is) + align_up((size_t)batch * ntiles * BIN_CAP * sizeof(int), 256) +
         align_up((size_t)batch * nf * sizeof(int), 256));
+    float* wide_rec = reinterpret_cast<float*>(reinterpret_cast<char*>(keys) + key_bytes(batch, is));
     const long total = (long)batch * nf;
     const bool splat = P->near_ >= 0.0f;            // the key order needs zp > 0, which the near test then guarantees
     if (!precleared) {   // both regions are 256-byte aligned and padded (bin_counter_bytes / key_bytes): whole uint4 stores
@@ -751,24 +917,25 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
     if (splat && setup) {
         if (setup->gather) hipLaunchKernelGGL(setup_splat_faces_kernel<true>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz,
                                               setup->fidx, setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list,
-                                              wide_count, wide_list, batch, nf, setup->nv, is, P->near_, P->far_);
+                                              wide_count, wide_list, wide_rec, batch, nf, setup->nv, is, P->near_, P->far_);
         else hipLaunchKernelGGL(setup_splat_faces_kernel<false>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz,
                                 setup->fidx, setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list,
-                                wide_count, wide_list, batch, nf, setup->nv, is, P->near_, P->far_);
+                                wide_count, wide_list, wide_rec, batch, nf, setup->nv, is, P->near_, P->far_);
         if (int e = check_launch("setup_splat_faces_kernel")) return e;
         P->keys = keys;
     } else if (splat) {
         hipLaunchKernelGGL(splat_faces_kernel, fgrid, dim3(256), 0, st, faces, faces_inv, boxes,
-                           keys, tile_count, tile_list, wide_count, wide_list, batch, nf, is, P->near_, P->far_);
+                           keys, tile_count, tile_list, wide_count, wide_list, wide_rec, batch, nf, is, P->near_, P->far_);
         if (int e = check_launch("splat_faces_kernel")) return e;
         P->keys = keys;
     } else {
         hipLaunchKernelGGL(bin_faces_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, faces, boxes, tile_count,
-                           tile_list, wide_count, wide_list, batch, nf, is);
+                           tile_list, wide_count, wide_list, wide_rec, batch, nf, is);
         if (int e = check_launch("bin_faces_kernel")) return e;
     }
     P->wide_count = wide_count;      // tested by the tile kernel (bin_wide_kernel's work, without its launch)
     P->wide_list = wide_list;
+    P->wide_rec = wide_rec;
     P->tile_count = tile_count;
     P->tile_list = tile_list;
     return 0;
