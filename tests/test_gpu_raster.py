@@ -172,14 +172,15 @@ def test_many_wide_faces_flush_path_vs_oracle(S, n_wide, n_plain, seed):
     assert (g['face_index_map'] >= 0).mean() > 0.3
 
 
-@pytest.mark.parametrize('S,seed', [(64, 31), (128, 32), (48, 33)])
-def test_zero_area_faces_through_pixel_centres_vs_oracle(S, seed):
+@pytest.mark.parametrize('S,seed,near', [(64, 31, 0.0), (128, 32, 0.0), (48, 33, 0.0), (50, 34, 0.0), (64, 35, -1.0)])
+def test_zero_area_faces_through_pixel_centres_vs_oracle(S, seed, near):
     """raster_tile_kernel walks a zero-area wide face (two coincident vertices) along its line and tests the two pixels next to
     the crossing of every row / column instead of all 256 pixels of the tile (r06).  Here the lines pass EXACTLY through pixel
     centres (both vertices sit on centres, rational slopes; at S = 64 / 128 every product of the edge tests is exact), so the
     reference's inside test passes on many pixels and the inf / NaN barycentric arithmetic behind it runs: all three
     coincidence patterns, steep / shallow / axis-parallel lines, end points far outside the image, faces beyond the walk's
-    coordinate bound (|x| > 4: ordinary queue entries), ordinary faces in front and behind.  Bit-exact against the oracle."""
+    coordinate bound (|x| > 4: ordinary queue entries), ordinary faces in front and behind; S = 50: edge tiles clipped by the
+    image; near < 0: the binning path without per-pixel keys, where no face is walked.  Bit-exact against the oracle."""
     from oracle import raster as oras
     rng = np.random.RandomState(seed)
     n_line, n_plain = 360, 120
@@ -201,7 +202,7 @@ def test_zero_area_faces_through_pixel_centres_vs_oracle(S, seed):
         k[:20] = 40 * S                                   # end point beyond |x| = 4: not walked, an ordinary wide-list entry
         a = np.stack([centre(i0), centre(j0)], -1)
         bb = np.stack([centre(i0 + p * k), centre(j0 + q * k)], -1)
-        if S == 48:                                       # not a power of two: nudge half of them off the exact centres
+        if S in (48, 50):                                 # not a power of two: nudge half of them off the exact centres
             bb[::2] += rng.uniform(-1e-6, 1e-6, size=bb[::2].shape).astype(np.float32)
         pat = rng.randint(0, 3, n_line)                   # which two vertices coincide: (0,1) (1,2) (2,0)
         for t in range(n_line):
@@ -210,8 +211,8 @@ def test_zero_area_faces_through_pixel_centres_vs_oracle(S, seed):
                 f[b, t, vtx, :2] = xy[vtx]
     perm = rng.permutation(nf)
     f = f[:, perm]
-    g = oras.face_index_map(f, S, 0.0, 1e5)
-    r = run_hip_raster(f, S, 0.0, 1e5)
+    g = oras.face_index_map(f, S, near, 1e5)
+    r = run_hip_raster(f, S, near, 1e5)
     assert_same(r, g)
     # (Evaluated without FMA contraction such a face has den == 0 exactly, its barycentric rows are +-inf / NaN, and a pixel
     # that passes the inside test gets inf - inf = NaN weights and a NaN depth: it never wins.  The walk must not invent a
