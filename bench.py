@@ -786,9 +786,26 @@ def main(argv=None):
             ser['events_span_ms'] = ev_s[0].elapsed_time(ev_e[K - 1])
         return dt_, ser, img_
 
+    def calibrate():
+        """What every rank's GPU sustains right now in a register-resident f32-MFMA loop (rnr_calibrate_mfma_f32, ~0.1 s):
+        [TFLOP/s per rank] or None.  Outside every timed region.  Boxes of one pool differ by several per cent in the
+        clock they hold under matrix load (r06: 552 / 577 / 580 frames/s from the same commit on three boxes): the
+        headline is only comparable across boxes beside this figure."""
+        if stub:
+            return None
+        from rnr_amd import ops
+        tf = ops.calibrate_mfma_f32(dev, 0.1)['tflops']
+        if not use_dist:
+            return [tf]
+        mine = torch.tensor([tf], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        return [float(t.item()) for t in allr]
+
     n_windows = 1 if stub else max(1, args.windows)
     windows = []
     img = None
+    calib_before = calibrate()
     for w in range(n_windows):
         dt_w, ser_w, img = timed_window()
         if use_dist:
@@ -796,6 +813,7 @@ def main(argv=None):
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_w = float(tmax.item())
         windows.append((dt_w, ser_w))
+    calib_after = calibrate()
     # value policy: the MEDIAN window (by max-over-ranks wall time) of n_windows windows of exactly K steps each; every
     # window's rate is printed (`windows`), the series below belong to the window `value` is taken from
     order = sorted(range(n_windows), key=lambda i: windows[i][0])
@@ -901,6 +919,14 @@ def main(argv=None):
                                        'foreground pixel when --tile-skip is given (never read: the ray renderer zeroes background)'
                                        % (flops_view / 1e9)},
         }
+        if calib_before is not None:
+            res['box_calibration'] = {
+                'instruction': 'v_mfma_f32_32x32x2_f32, register-resident loop on every SIMD (rnr_calibrate_mfma_f32, ~0.1 s per measurement)',
+                'nominal_tflops': EMU_PEAK['f32'], 'tflops_per_rank_before_windows': calib_before,
+                'tflops_per_rank_after_windows': calib_after,
+                'frac_of_nominal': min(calib_before + calib_after) / EMU_PEAK['f32'],
+                'note': 'what THIS box sustains on the U-Net\'s instruction around the timed windows; the same commit measured 552, 577 and '
+                        '580 frames/s on three boxes of the pool in r06 — compare `value` across boxes beside this number'}
         if stub:
             res['stub'] = True
             res['cpu_baseline'] = None

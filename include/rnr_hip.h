@@ -543,6 +543,16 @@ int rnr_obj_scan(const char* text, size_t len, rnr_obj_counts* counts);
 int rnr_obj_parse(const char* text, size_t len, const rnr_obj_counts* counts, float* v, float* vn, float* vt,
                   int32_t* f_v_idx, int32_t* f_vt_idx, int32_t* f_vn_idx);
 
+/* =====================================================================================================
+ * 5. Measurement aid (bench.py's `box_calibration`; no counterpart in the reference).
+ *    rnr_calibrate_mfma_f32 runs `iters` x 32 register-resident v_mfma_f32_32x32x2_f32 per wave on every SIMD of the
+ *    current device (`waves_per_simd` = 1 ... 8 waves per SIMD, full-mantissa operands, no memory traffic), times the launch with HIP events
+ *    on `stream`, waits for it, and returns the rate in *tflops (and the duration in *seconds, if not NULL): what this
+ *    device sustains NOW on the instruction the U-Net runs on (nominal 157.3 TFLOP/s).  scratch: >= 4 bytes of device
+ *    memory (never written in practice).  Blocks the calling thread.
+ * ===================================================================================================== */
+int rnr_calibrate_mfma_f32(int iters, int waves_per_simd, float* scratch, double* tflops, double* seconds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,7 @@ SIGNATURES = {
     'rnr_interpolate_bilinear': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p]),
     'rnr_resize_area': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'rnr_calibrate_mfma_f32': (c_int, [c_int, c_int, c_void_p, P(ctypes.c_double), P(ctypes.c_double), c_void_p]),
     'rnr_obj_scan': (c_int, [ctypes.c_char_p, c_size_t, P(RnrObjCounts)]),
     'rnr_obj_parse': (c_int, [ctypes.c_char_p, c_size_t, P(RnrObjCounts)] + [c_void_p] * 6),
     'rnr_view_dir_map': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -392,6 +392,20 @@ def ray_weights(net_in, alpha, lp, num_spec, num_diff, c_w, albedo_diff_ch=0, al
     return out
 
 
+def calibrate_mfma_f32(device='cuda:0', seconds=0.1, waves_per_simd=2):
+    """TFLOP/s this device sustains NOW in a register-resident v_mfma_f32_32x32x2_f32 loop on every SIMD
+    (rnr_calibrate_mfma_f32; nominal 157.3): a probe call sizes the loop for about `seconds`.  Blocks."""
+    L = _lib.load()
+    with on_device(device):
+        scratch = torch.zeros(16, dtype=torch.float32, device=device)
+        tf, dt = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check(L.rnr_calibrate_mfma_f32(256, int(waves_per_simd), _ptr(scratch), ctypes.byref(tf), ctypes.byref(dt), _stream()))
+        per_iter = max(dt.value, 1e-6) / 256.0
+        iters = int(min(max(seconds / per_iter, 256), 4e6))
+        check(L.rnr_calibrate_mfma_f32(iters, int(waves_per_simd), _ptr(scratch), ctypes.byref(tf), ctypes.byref(dt), _stream()))
+    return {'tflops': tf.value, 'seconds': dt.value, 'iters': iters, 'waves_per_simd': int(waves_per_simd)}
+
+
 @_device_op
 def sh_basis(dirs, lmax):
     """sph_harm.evaluate_sh_basis: dirs [n,3] -> [n,(lmax+1)^2] float32."""

@@ -41,6 +41,11 @@ def test_bench_under_torchrun_rccl_gather():
     assert len(ss['step_ms']) == 2 and len(ss['gap_ms']) == 1 and len(ss['unet_ms']) == 2 and len(ss['host_enqueue_ms']) == 2
     assert all(u < t for u, t in zip(ss['unet_ms'], ss['step_ms'])) and ss['ms_per_step_min'] <= ss['ms_per_step_median'] <= ss['ms_per_step_max']
     assert ss['non_unet_ms_per_step'] > 0 and isinstance(ss['slow_steps'], list) and res['prewarm_steps'] >= 1
+    # r06: what this box sustains on the U-Net's MFMA instruction, measured around the timed windows (one figure per rank)
+    bc = res['box_calibration']
+    assert len(bc['tflops_per_rank_before_windows']) == len(bc['tflops_per_rank_after_windows']) == 1
+    assert 0.5 < bc['frac_of_nominal'] < 1.02 and bc['nominal_tflops'] == 157.3
+    assert res['roofline']['frac'] < bc['frac_of_nominal']          # no kernel beats the register-resident loop
 
 
 def test_bench_plain_launch_forced_dist():
