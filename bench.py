@@ -74,6 +74,8 @@ def parse(argv=None):
                          'frames it rendered (bitwise) and report it as gather_check (tests/test_gpu_dist.py)')
     ap.add_argument('--main-loop-only', action='store_true',
                     help='skip the per-stage and single-view extras after the timed loop (rocprofv3 runs: every kernel launch in the profile then belongs to a timed or warm-up step)')
+    ap.add_argument('--no-calibration', action='store_true',
+                    help='skip box_calibration (rocprofv3 runs: its register-resident MFMA loop would be half of the kernel statistics)')
     ap.add_argument('--single-views', type=int, default=720,
                     help='views of the single_view_mode block (default: the whole spiral_step720 trajectory, as test_rnr.py renders it)')
     ap.add_argument('--no-dropin-loop', action='store_true', help='skip the dropin_view_loop block (INTEGRATION.md Level 1 timing)')
@@ -294,7 +296,7 @@ def pmc_mfma_flops_per_step(info):
     steps = meta.get('steps', 2) + meta.get('warmup', 1)
     tot = 0.0
     for k, v in prof.items():
-        if k == '_meta' or 'SQ_INSTS_MFMA_total' not in v:
+        if k == '_meta' or 'SQ_INSTS_MFMA_total' not in v or 'conv_' not in k:      # the convolutions only (not calibrate_mfma_f32_kernel)
             continue
         tot += v['SQ_INSTS_MFMA_total'] * (2048.0 if 'conv_wino80' in k else 4096.0)
     return tot / steps if tot > 0 else None
@@ -791,7 +793,7 @@ def main(argv=None):
         [TFLOP/s per rank] or None.  Outside every timed region.  Boxes of one pool differ by several per cent in the
         clock they hold under matrix load (r06: 552 / 577 / 580 frames/s from the same commit on three boxes): the
         headline is only comparable across boxes beside this figure."""
-        if stub:
+        if stub or args.no_calibration:
             return None
         from rnr_amd import ops
         tf = ops.calibrate_mfma_f32(dev, 0.1)['tflops']

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/bench.py --conv-algo $CONV_ALGO --views-per-step $VIEWS --steps $PMC_STEPS --warmup $PMC_WARMUP --no-cpu-baseline --no-parity --main-loop-only --prewarm-seconds 0 --windows 1 --precision $PRECISION > $OUT/p$i.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/bench.py --conv-algo $CONV_ALGO --views-per-step $VIEWS --steps $PMC_STEPS --warmup $PMC_WARMUP --no-cpu-baseline --no-parity --main-loop-only --no-calibration --prewarm-seconds 0 --windows 1 --precision $PRECISION > $OUT/p$i.log 2>&1
   i=$((i+1))
 done
 python $GRAFT_REPO_ROOT/scripts/pmc_merge.py $OUT

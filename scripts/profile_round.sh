@@ -19,7 +19,7 @@ for cfg in $CFGS; do
   name=$prec; [ $prec = f32 ] && [ $algo = direct ] && name=f32_direct; [ $prec = f32 ] && [ $algo = winograd ] && name=f32_f2x2only
   steps=5; [ $v = 1 ] && steps=20
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_${name}_$v -- python $ROOT/bench.py --steps $steps --warmup 2 \
-      --views-per-step $v --no-cpu-baseline --main-loop-only --prewarm-seconds 0 --windows 1 --precision $prec --conv-algo $algo > $OUT/kt_${name}_$v.log 2>&1
+      --views-per-step $v --no-cpu-baseline --main-loop-only --no-calibration --prewarm-seconds 0 --windows 1 --precision $prec --conv-algo $algo > $OUT/kt_${name}_$v.log 2>&1
   find $OUT/kt_${name}_$v -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats_${name}_steps${steps}_views$v.csv
   [ $v = 1 ] && find $OUT/kt_${name}_$v -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_trace_views1.csv
   grep "^{\"metric\"" $OUT/kt_${name}_$v.log | tail -1 > $OUT/${TAG}_bench_line_under_profiler_${name}_views$v.json
