@@ -220,13 +220,16 @@ def test_zero_area_faces_through_pixel_centres_vs_oracle(S, seed, near):
     assert (g['face_index_map'] >= 0).mean() > 0.3
 
 
-def test_sphere_512_vs_oracle():
-    """BASELINE config size: 65 536-face UV sphere at 512^2 (includes the zero-area pole faces)."""
+@pytest.mark.parametrize('view', [100, 162])
+def test_sphere_512_vs_oracle(view):
+    """BASELINE config size: 65 536-face UV sphere at 512^2 (includes the zero-area pole faces).  View 162 looks at a pole
+    edge-on: ~250 sliver faces with boxes above 256 pixels are binned into a handful of tiles (215 candidates in one), 66
+    non-degenerate slivers ride the wide list beside the 512 zero-area faces whose lines all cross the pole's tile."""
     from oracle import raster as oras
     from oracle import rnr_oracle as orc
     from rnr_amd import scene
     mesh = scene.uv_sphere(128, 256)
-    v = scene.spiral_views(512, [100])
+    v = scene.spiral_views(512, [view])
     uvz = orc.projection(torch.from_numpy(mesh['v'])[None], torch.from_numpy(v['proj']), torch.from_numpy(v['pose'][:, :3, :3]),
                          torch.from_numpy(v['pose'][:, :3, 3])[:, None, :], torch.zeros(1, 5), 512)
     faces = orc.gather_faces(uvz, torch.from_numpy(mesh['f_v_idx'])[None]).numpy()
