@@ -70,7 +70,7 @@ template <bool GATHER>
 __device__ __forceinline__ bool face_setup(long i, const float* __restrict__ faces_in, const float* __restrict__ v_uvz,
                                            const int32_t* __restrict__ fidx, float* __restrict__ faces_out,
                                            float* __restrict__ faces_inv, FaceBox* __restrict__ boxes, int nf, int nv, int is,
-                                           float (&f)[9], float (&inv)[9], FaceBox& box) {
+                                           float (&f)[9], float (&inv)[9], FaceBox& box, bool write = true) {
     if (GATHER) {  // vertices_to_faces.py:4-25 fused in
         const int bn = (int)(i / nf), fn = (int)(i % nf);
 #pragma unroll
@@ -82,15 +82,15 @@ __device__ __forceinline__ bool face_setup(long i, const float* __restrict__ fac
             f[3 * v + 2] = p[2];
         }
 #pragma unroll
-        for (int k = 0; k < 9; k++) faces_out[i * 9 + k] = f[k];
+        for (int k = 0; k < 9; k++) if (write) faces_out[i * 9 + k] = f[k];
     } else {
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = faces_in[i * 9 + k];
     }
     if (backface(f)) {  // reference returns before writing: caller's zero fill stays (rasterize.py:163)
         box = empty_box();
-        boxes[i] = box;
-        if (GATHER) {
+        if (write) boxes[i] = box;
+        if (GATHER && write) {
 #pragma unroll
             for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = 0.0f;
         }
@@ -110,7 +110,7 @@ __device__ __forceinline__ bool face_setup(long i, const float* __restrict__ fac
     m[6] = py[0] - py[1]; m[7] = px[1] - px[0]; m[8] = px[0] * py[1] - px[1] * py[0];
     const float den = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
 #pragma unroll
-    for (int k = 0; k < 9; k++) { inv[k] = m[k] / den; faces_inv[i * 9 + k] = inv[k]; }
+    for (int k = 0; k < 9; k++) { inv[k] = m[k] / den; if (write) faces_inv[i * 9 + k] = inv[k]; }
 
     // ---- conservative pixel bounding box (double; DESIGN.md §Rasterizer gives the bound) ----
     const double x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
@@ -145,7 +145,7 @@ __device__ __forceinline__ bool face_setup(long i, const float* __restrict__ fac
             box.xlo = (short)lx; box.xhi = (short)hx; box.ylo = (short)ly; box.yhi = (short)hy;
         }
     }
-    boxes[i] = box;
+    if (write) boxes[i] = box;
     return true;
 }
 
@@ -296,11 +296,11 @@ constexpr unsigned long long KEY_EMPTY = ~0ull;
 // division sequence per pixel.
 template <bool POW2>
 __device__ __forceinline__ void splat_pixels(const float4 r0, const float4 r1, const float4 r2, const float4 r3, const float4 r4,
-                                             const float4 r5, int xa, int xb, int ya, int yb, int fn,
+                                             const float4 r5, int xa, int xb, int ya, int yb, int ystep, int fn,
                                              unsigned long long* __restrict__ kv, int is, float near_, float far_) {
     const float inv_is = 1.0f / (float)is;
     auto center = [&](int i) { return POW2 ? (float)(2 * i + 1 - is) * inv_is : pix_center(i, is); };
-    for (int yi = ya; yi <= yb; yi++) {
+    for (int yi = ya; yi <= yb; yi += ystep) {
         const float yp = center(yi);
         for (int xc = xa; xc <= xb; xc += 32) {
             const int xe = min(xb, xc + 31);
@@ -325,10 +325,14 @@ template <typename FP>
 __device__ __forceinline__ void splat_face(long i, int bn, int fn, const FaceBox b, FP f, FP fi,
                                            unsigned long long* __restrict__ keys, int* __restrict__ tile_count,
                                            int* __restrict__ tile_list, int* __restrict__ wide_count, int* __restrict__ wide_list,
-                                           float* __restrict__ wide_rec, int nf, int is, float near_, float far_) {
+                                           float* __restrict__ wide_rec, int nf, int is, float near_, float far_, int sub = 0,
+                                           int nsub = 1) {
+    // sub / nsub: this lane is one of nsub that share the face (setup_splat_faces_kernel<., LPF>): it walks the box rows
+    // sub, sub + nsub, ...; lane 0 alone bins / lists a face that is not walked
     if (b.xlo != BOX_EXACT && b.xlo > b.xhi) return;                    // empty_box(): culled / off-screen
     const int xa = max((int)b.xlo, 0), xb = b.xhi, ya = max((int)b.ylo, 0), yb = b.yhi;
     if (b.xlo == BOX_EXACT || (xb - xa + 1) * (yb - ya + 1) > SPLAT_MAX_PIX) {
+        if (sub != 0) return;
         // too big to walk pixel by pixel.  A trusted box over a few tiles is binned right here (bin_faces_kernel's loop);
         // only untrusted boxes and huge faces take the wide list, whose faces the tile kernel tests against
         // EVERY tile — with every > 256-pixel face on it, a close-up of a coarse mesh cost wide x tiles pair tests
@@ -353,8 +357,8 @@ __device__ __forceinline__ void splat_face(long i, int bn, int fn, const FaceBox
     const float4 r4 = make_float4(fi[4], fi[5], fi[6], fi[7]);
     const float4 r5 = make_float4(fi[8], z0, z1, z2);
     unsigned long long* kv = keys + (size_t)bn * is * is;
-    if ((is & (is - 1)) == 0) splat_pixels<true>(r0, r1, r2, r3, r4, r5, xa, xb, ya, yb, fn, kv, is, near_, far_);
-    else splat_pixels<false>(r0, r1, r2, r3, r4, r5, xa, xb, ya, yb, fn, kv, is, near_, far_);
+    if ((is & (is - 1)) == 0) splat_pixels<true>(r0, r1, r2, r3, r4, r5, xa, xb, ya + sub, yb, nsub, fn, kv, is, near_, far_);
+    else splat_pixels<false>(r0, r1, r2, r3, r4, r5, xa, xb, ya + sub, yb, nsub, fn, kv, is, near_, far_);
 }
 
 __global__ void __launch_bounds__(256)
@@ -372,20 +376,26 @@ splat_faces_kernel(const float* __restrict__ faces, const float* __restrict__ fa
 // but its own face's record, which it takes from the registers of the setup — the same values the setup writes for the tile
 // kernel, hence the same bits as the two launches (tests/test_gpu_raster.py).
 struct FaceSetupArgs { const float* faces_in; const float* v_uvz; const int32_t* fidx; float* faces_out; int nv; int gather; };
-template <bool GATHER>
+// LPF lanes per face (r06): with a single view in the launch two thirds of the waves hold back faces only and leave at once,
+// the others walk ~30 pixels per lane at one wave per SIMD; four lanes per face (each repeats the setup — same instructions,
+// lane 0 stores — and walks every fourth box row) spread the live faces over four times the waves: 23.8 -> 15.7 us per 512^2 view.
+// Batches that fill the chip anyway keep one lane per face.
+template <bool GATHER, int LPF>
 __global__ void __launch_bounds__(256)
 setup_splat_faces_kernel(const float* __restrict__ faces_in, const float* __restrict__ v_uvz, const int32_t* __restrict__ fidx,
                          float* __restrict__ faces_out, float* __restrict__ faces_inv, FaceBox* __restrict__ boxes,
                          unsigned long long* __restrict__ keys, int* __restrict__ tile_count, int* __restrict__ tile_list,
                          int* __restrict__ wide_count, int* __restrict__ wide_list, float* __restrict__ wide_rec, int batch,
                          int nf, int nv, int is, float near_, float far_) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = t / LPF;
+    const int sub = (int)(t % LPF);
     if (i >= (long)batch * nf) return;
     float f[9], inv[9];
     FaceBox box;
-    if (!face_setup<GATHER>(i, faces_in, v_uvz, fidx, faces_out, faces_inv, boxes, nf, nv, is, f, inv, box)) return;
+    if (!face_setup<GATHER>(i, faces_in, v_uvz, fidx, faces_out, faces_inv, boxes, nf, nv, is, f, inv, box, sub == 0)) return;
     splat_face<const float (&)[9]>(i, (int)(i / nf), (int)(i % nf), box, f, inv, keys, tile_count, tile_list, wide_count,
-                                   wide_list, wide_rec, nf, is, near_, far_);
+                                   wide_list, wide_rec, nf, is, near_, far_, sub, LPF);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -915,12 +925,17 @@ static int run_binning(char* ws, const float* faces, const float* faces_inv, con
         if (int e = check_launch("face_setup_kernel")) return e;
     }
     if (splat && setup) {
-        if (setup->gather) hipLaunchKernelGGL(setup_splat_faces_kernel<true>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz,
-                                              setup->fidx, setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list,
-                                              wide_count, wide_list, wide_rec, batch, nf, setup->nv, is, P->near_, P->far_);
-        else hipLaunchKernelGGL(setup_splat_faces_kernel<false>, fgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz,
-                                setup->fidx, setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list,
-                                wide_count, wide_list, wide_rec, batch, nf, setup->nv, is, P->near_, P->far_);
+        // lanes per face: four while the launch would otherwise leave most SIMDs with one wave or none (RNR_SPLAT_LPF overrides)
+        static const int forced = [] { const char* e = getenv("RNR_SPLAT_LPF"); return e ? atoi(e) : 0; }();
+        const int lpf = forced == 1 || forced == 4 ? forced : (total <= 2 * 65536 ? 4 : 1);
+        const dim3 sgrid((unsigned)((total * lpf + 255) / 256));
+#define RNR_LAUNCH_SETUP_SPLAT(G, L)                                                                                            \
+        hipLaunchKernelGGL((setup_splat_faces_kernel<G, L>), sgrid, dim3(256), 0, st, setup->faces_in, setup->v_uvz, setup->fidx, \
+                           setup->faces_out, faces_inv_w, boxes_w, keys, tile_count, tile_list, wide_count, wide_list, wide_rec,  \
+                           batch, nf, setup->nv, is, P->near_, P->far_)
+        if (setup->gather) { if (lpf == 4) RNR_LAUNCH_SETUP_SPLAT(true, 4); else RNR_LAUNCH_SETUP_SPLAT(true, 1); }
+        else { if (lpf == 4) RNR_LAUNCH_SETUP_SPLAT(false, 4); else RNR_LAUNCH_SETUP_SPLAT(false, 1); }
+#undef RNR_LAUNCH_SETUP_SPLAT
         if (int e = check_launch("setup_splat_faces_kernel")) return e;
         P->keys = keys;
     } else if (splat) {
