@@ -188,12 +188,14 @@ __device__ __forceinline__ double* stat_slot(const ConvParams& P, int n, int col
 // The (sum, sum of squares) pair of a channel is one 16-byte sc1 load per shard — L1-bypassing like the 8-byte agent-scope
 // atomic load, but all STAT_SHARDS of them are in flight at once (a chain of __hip_atomic_load is issued one at a time:
 // 16 round trips, 20 us at the end of a 150 us kernel) — and one 16-byte sc1 store of zeros.
-__device__ __forceinline__ void bn_finalize_views(const ConvParams& P, int n_first, int n_views, int tid) {
+__device__ __forceinline__ void bn_finalize_views(const ConvParams& P, int n_first, int n_views, int tid, int i_first = 0,
+                                                  int i_stride = 0) {
     const int total = n_views * P.c_out_pad;
+    const int stride = i_stride ? i_stride : (int)blockDim.x;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(P.stats, 0, 0x7fffffff, 0x27000);
     const uintx4_t zero4 = {0u, 0u, 0u, 0u};
     typedef double doublex2 __attribute__((ext_vector_type(2)));
-    for (int i = tid; i < total; i += (int)blockDim.x) {
+    for (int i = i_first + tid; i < total; i += stride) {
         const int idx = n_first * P.c_out_pad + i;
         const int c = i % P.c_out_pad;
         doublex2 part[STAT_SHARDS];
@@ -1559,9 +1561,11 @@ splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int spli
 // rnr_conv2d_fused's BatchNorm as its own launch: convolutions whose workgroups all finish together (one workgroup per CU,
 // the split-K reduce kernel) gain nothing from drawing tickets — three dependent round trips at the end of the kernel cost
 // more than the 4.7 us of this launch (measured at one view per call: +8 ... +15 us on the 256-workgroup layers).
+// One workgroup per (view, 256 channels): every thread has ONE channel, its eight shard loads in flight together (a single
+// workgroup per view walked 512 channels in two dependent rounds: 1.5 us of the 4.7, r06).
 __global__ void __launch_bounds__(CTHREADS)
 bn_finalize_shards_kernel(const ConvParams P) {
-    bn_finalize_views(P, blockIdx.x, 1, threadIdx.x);
+    bn_finalize_views(P, blockIdx.x, 1, threadIdx.x, (int)(blockIdx.y * blockDim.x), (int)(gridDim.y * blockDim.x));
 }
 
 template <bool RESET>
@@ -2383,7 +2387,8 @@ static int conv2d_run(const rnr_conv_desc* d, const rnr_conv_src* src0, const rn
         if (int e = check_launch("splitk_reduce_kernel")) return e;
     }
     if (with_bn && !in_kernel_bn) {
-        hipLaunchKernelGGL(bn_finalize_shards_kernel, dim3((unsigned)num_views), dim3(CTHREADS), 0, st, P);
+        hipLaunchKernelGGL(bn_finalize_shards_kernel, dim3((unsigned)num_views, (unsigned)((d->c_out_pad + CTHREADS - 1) / CTHREADS)),
+                           dim3(CTHREADS), 0, st, P);
         if (int e = check_launch("bn_finalize_shards_kernel")) return e;
     }
     return 0;
