@@ -15,11 +15,15 @@
 //      covers <= 256 pixels walks them itself and folds (depth bits, face index) into a per-pixel 64-bit key
 //      with one atomicMin; a bigger trusted box is binned into the 16x16-pixel tiles it touches (exact,
 //      rounding-monotone tile test); untrusted boxes and huge faces go to a per-view wide list, which
-//      every tile of raster_tile_kernel tests against itself.  (near < 0: bin_faces_kernel bins everything.)
+//      every tile of raster_tile_kernel tests against itself (records of six coordinates + index, 1024 per round
+//      trip).  (near < 0: bin_faces_kernel bins everything.)  With at most two views in the launch four lanes share
+//      a face (box rows modulo 4).
 //   3. raster_tile_kernel, one 256-thread workgroup per tile: evaluates the reference's per-candidate
 //      arithmetic for its binned candidates on LDS-broadcast face records — unordered lists, so the
 //      reference's "ascending faces, strict <" rule is applied in its order-free form (smallest zp, ties ->
-//      smallest face index) — merges the winner with the pixel's key, and writes either the extension's maps
+//      smallest face index) —, walks the zero-area wide faces (two coincident vertices: the pole faces of a UV sphere)
+//      along their line — only the two pixels next to the line's crossing of a row / column can pass the reference's
+//      inside test, see walk_lines —, merges the winner with the pixel's key, and writes either the extension's maps
 //      (drop-in mode) or the perspective-corrected attribute interpolation of network.py:176-214, already
 //      vertically flipped.  A tile whose list overflowed rescans every face box itself (the in-order ballot
 //      scan of round 1, kept as the fallback: capacity never changes results).
