@@ -2132,10 +2132,15 @@ extern "C" int rnr_pack_conv_weight(const rnr_conv_desc* d, const float* weight,
     return 0;
 }
 
-// split-K slices of a tile meet inside the launch (splitk_combine) when there are few of them: the last slice reads
+// split-K slices of a tile can meet inside the launch (splitk_combine) when there are few of them: the last slice reads
 // splitk accumulator images, a serial tail that a chip-wide reduce kernel beats for deep splits
+// OFF since r06 (RNR_CONV_COMBINE=1 in the environment turns it on): re-measured at one view per call, slabs + reduce kernel
+// beat the in-launch form on every layer that took it (L11 46.9 -> 33.2 us, L12 31.4 -> 29.8, frame 449.0 -> 452.2 frames/s;
+// equal from three views on) — the last slices of all tiles fetch their images past the L2 at the same moment behind two fabric
+// round trips, a chip-wide reduce reads the same bytes at 4 - 5 TB/s (profiles/r06_one_view_frontend.txt (3), (5)).
 static bool combines_in_launch(const ConvPlan& pl) {
-    return pl.halo && !pl.wino && pl.splitk > 1 && pl.cfg != 1 && pl.bm * pl.bn <= 128 * 128 &&
+    static const int enabled = [] { const char* e = getenv("RNR_CONV_COMBINE"); return e ? atoi(e) : 0; }();
+    return enabled && pl.halo && !pl.wino && pl.splitk > 1 && pl.cfg != 1 && pl.bm * pl.bn <= 128 * 128 &&
            (long)pl.splitk * pl.bm * pl.bn * (long)sizeof(float) <= RNR_COMBINE_MAX_BYTES;
 }
 static size_t combine_slab_floats(const ConvPlan& pl) {     // one accumulator image per (slice, tile): bm x bn floats

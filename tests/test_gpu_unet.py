@@ -215,6 +215,21 @@ CASES = [
 ]
 
 
+def test_conv_fused_with_in_launch_combine_opt_in():
+    """The in-launch split-K combine is off by default since r06 (slabs + reduce kernel measured faster at one view per call);
+    RNR_CONV_COMBINE=1 turns it on.  The library reads the switch once per process, so the split cases of the test above run
+    again in a process of their own with the switch set: same bit-exact comparisons."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RNR_CONV_COMBINE='1')
+    p = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-m', 'gpu', '-x', '-q', '-k',
+                        'test_conv_fused_equals_separate_launches and (cins0 or cins1 or cins2 or cins3 or cins5)'], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert ' passed' in p.stdout and 'deselected' in p.stdout
+
+
 @pytest.mark.parametrize('kind,N,H,W,cins,c_out', CASES)
 def test_conv_vs_torch(kind, N, H, W, cins, c_out):
     g = torch.Generator().manual_seed(kind * 100 + H + c_out)
