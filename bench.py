@@ -507,7 +507,7 @@ def single_view_block(sc, args, dev):
         'frames_per_s': 1.0 / dt_seq, 'ms_per_frame': dt_seq * 1e3,
         'roofline': {'bound': 'mfma', 'kernel': 'conv_wino4_kernel / conv_wino_kernel / conv_wino2p_kernel / conv_wino2_kernel / conv_halo_kernel (22 conv launches per view; the split-K Winograd layers are '
                                                   'followed by a reduce launch and the one-workgroup-per-CU grids by a BatchNorm finalise launch of their own: '
-                                                  '12 + 13 launches at 512^2, profiles/r06_frame_timeline_f32_views1.txt; HIP events bracket the U-Net stage of every call)',
+                                                  '14 + 14 launches at 512^2, profiles/r06_frame_timeline_f32_views1.txt; HIP events bracket the U-Net stage of every call)',
                      **algo1, 'stage_ms_per_view': unet_ms, **sustained_block(args.precision, algo1['achieved']),
                      'alg_flops_per_view': flops_view, 'traffic': traffic,
                      'traffic_unit': 'bytes/view (HBM-side, PMC: (2 x FETCH_SIZE + WRITE_SIZE) KB of the conv kernels)',
