@@ -797,12 +797,25 @@ def main(argv=None):
             return None
         from rnr_amd import ops
         tf = ops.calibrate_mfma_f32(dev, 0.1)['tflops']
+        # ... and a device-to-device copy of 512 MiB (read + write counted), best of five: the HBM side of the same question
+        a = torch.empty(128 << 20, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            best = max(best, 2.0 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
         if not use_dist:
-            return [tf]
-        mine = torch.tensor([tf], device=dev, dtype=torch.float64)
+            return [(tf, best)]
+        mine = torch.tensor([tf, best], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        return [float(t.item()) for t in allr]
+        return [(float(t[0].item()), float(t[1].item())) for t in allr]
 
     n_windows = 1 if stub else max(1, args.windows)
     windows = []
@@ -924,9 +937,12 @@ def main(argv=None):
         if calib_before is not None:
             res['box_calibration'] = {
                 'instruction': 'v_mfma_f32_32x32x2_f32, register-resident loop on every SIMD (rnr_calibrate_mfma_f32, ~0.1 s per measurement)',
-                'nominal_tflops': EMU_PEAK['f32'], 'tflops_per_rank_before_windows': calib_before,
-                'tflops_per_rank_after_windows': calib_after,
-                'frac_of_nominal': min(calib_before + calib_after) / EMU_PEAK['f32'],
+                'nominal_tflops': EMU_PEAK['f32'], 'tflops_per_rank_before_windows': [c[0] for c in calib_before],
+                'tflops_per_rank_after_windows': [c[0] for c in calib_after],
+                'frac_of_nominal': min(c[0] for c in calib_before + calib_after) / EMU_PEAK['f32'],
+                'hbm_copy_GBps_per_rank_before_windows': [c[1] for c in calib_before],
+                'hbm_copy_GBps_per_rank_after_windows': [c[1] for c in calib_after],
+                'hbm_copy': 'torch device-to-device copy of 512 MiB, bytes read + written, best of five',
                 'note': 'what THIS box sustains on the U-Net\'s instruction around the timed windows; the same commit measured 552, 577 and '
                         '580 frames/s on three boxes of the pool in r06 — compare `value` across boxes beside this number'}
         if stub:

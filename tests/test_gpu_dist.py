@@ -45,6 +45,7 @@ def test_bench_under_torchrun_rccl_gather():
     bc = res['box_calibration']
     assert len(bc['tflops_per_rank_before_windows']) == len(bc['tflops_per_rank_after_windows']) == 1
     assert 0.5 < bc['frac_of_nominal'] < 1.02 and bc['nominal_tflops'] == 157.3
+    assert len(bc['hbm_copy_GBps_per_rank_before_windows']) == 1 and 1000.0 < bc['hbm_copy_GBps_per_rank_after_windows'][0] < 8000.0
     assert res['roofline']['frac'] < bc['frac_of_nominal']          # no kernel beats the register-resident loop
 
 
